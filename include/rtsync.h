@@ -1,0 +1,137 @@
+/*
+ * rtsync.h -- C-ABI of librtsync.so: the MI355X (gfx950) implementation of the chroma + DTW /
+ * online-time-warping / windowed-time-warping hot path of smritip/real-time-audio-sync.
+ *
+ * The reference has no FFI boundary of its own (it is plain in-process Python); each entry point
+ * below names the reference interface it replaces (file:line under /root/reference).  The Python
+ * classes in real_time_audio_sync_amd/ bind these symbols with ctypes and keep the reference's
+ * call surface (INTEGRATION.md shows the binding a maintainer would add).
+ *
+ * Conventions
+ *   - All `*_dev` pointers are device (HIP) pointers on the current device; the library never
+ *     frees or reallocates caller memory.  `stream` is a hipStream_t passed as void* (NULL =
+ *     the default stream).  Calls taking a stream are asynchronous on it; `*_read_*` getters
+ *     synchronise that stream and copy to host memory.
+ *   - Feature matrices are FRAME-MAJOR: [frame][feature], feature stride 1 (the reference's
+ *     numpy arrays are feature-major (12, N); the Python layer transposes once at upload).
+ *   - Return value: 0 = ok, < 0 = error (message via rts_last_error(), thread-local).
+ *   - One handle must not be driven from two host threads at once.
+ *   - There is no CPU fallback anywhere behind this header.
+ */
+#ifndef RTSYNC_H
+#define RTSYNC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTS_OK 0
+#define RTS_ERR_INVALID (-1)     /* bad argument (message says which) */
+#define RTS_ERR_UNSUPPORTED (-2) /* valid in the reference, not supported by this build (e.g. c too large) */
+#define RTS_ERR_HIP (-3)         /* a HIP runtime call failed */
+#define RTS_ERR_NO_DEVICE (-4)   /* no gfx950 device visible */
+
+/* dtype of feature / sample buffers handed to the library */
+#define RTS_F32 0
+#define RTS_F64 1
+
+/* which reference class an OTW handle follows */
+#define RTS_VARIANT_OTW 0         /* otw_eran.py:5   OnlineTimeWarping (sentinel 1e10, run_count starts 1) */
+#define RTS_VARIANT_LIVENOTE 1    /* livenote.py:3   LiveNote          (sentinel inf,  run_count starts 0) */
+#define RTS_VARIANT_LIVENOTE_V2 2 /* livenote_v2.py:3 LiveNoteV2       (+ forward-only path filter)       */
+
+#define RTS_COST_DOT 0    /* 1 - <live, ref>            otw_eran.py:220, livenote_v2.py:170 */
+#define RTS_COST_EUCLID 1 /* ||live - ref||_2           livenote_v2.py:168 (chroma_diff=True) */
+
+/* direction / previous codes in the state vector */
+#define RTS_DIR_NONE (-1)
+#define RTS_DIR_BOTH 0
+#define RTS_DIR_ROW 1
+#define RTS_DIR_COLUMN 2
+
+/* per-stream status (replaces insert()'s return value) */
+#define RTS_RUNNING 0
+#define RTS_STOP_REF_END 1  /* insert() returned "stop": otw_eran.py:69-71, livenote_v2.py:80-82 */
+#define RTS_LIVE_OVERFLOW 2 /* "ran out of room in pre-allocated live-sequence": otw_eran.py:53-55 */
+
+/* how rts_otw_run walks the live sequence */
+#define RTS_MODE_INSERT_LOOP 0 /* for i: insert(live[:, i])  (tests.py:160-163, test_simple.py:122-125) */
+#define RTS_MODE_SET_LIVE 1    /* set_live(live)             (otw_eran.py:91-142, livenote_v2.py:108-155) */
+
+/* layout of the int32 state vector returned by rts_otw_read_state (RTS_STATE_LEN entries) */
+#define RTS_STATE_LEN 16
+#define RTS_ST_T 0            /* t / live_ptr */
+#define RTS_ST_J 1            /* j / ref_ptr */
+#define RTS_ST_DIRECTION 2
+#define RTS_ST_PREVIOUS 3
+#define RTS_ST_RUN_COUNT 4
+#define RTS_ST_STATUS 5
+#define RTS_ST_FIRST_INSERT 6
+#define RTS_ST_N_PATH 7       /* path points recorded */
+#define RTS_ST_CONSUMED 8     /* live frames consumed (inserts made, incl. the one that stopped) */
+#define RTS_ST_ROW_STRIPS 9
+#define RTS_ST_COL_STRIPS 10
+#define RTS_ST_CELLS_LO 11    /* cells evaluated, low/high 32 bits */
+#define RTS_ST_CELLS_HI 12
+#define RTS_ST_PATH_TRUNCATED 13
+
+const char *rts_last_error(void);
+int rts_version(void);
+/* Number of visible HIP devices that are gfx950; < 0 on HIP failure. */
+int rts_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Online time warping, batched over B independent live streams against one reference.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rts_otw rts_otw;
+
+/* Replaces OnlineTimeWarping.__init__ (otw_eran.py:6-36) / LiveNote.__init__ (livenote.py:5-35) /
+ * LiveNoteV2.__init__ (livenote_v2.py:8-40) for B streams at once.  `ref_dev` ([N][F], dtype
+ * `ref_dtype`) is held by reference like otw_eran.py:17 and must outlive the handle.  Instead of the
+ * reference's dense (2N x N) cost/acc matrices the handle keeps two (c+1)-cell bands per stream.
+ * F must be 12.  Supported band widths: 1 <= c <= 500. */
+int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int c, int max_run_count,
+                   int variant, int cost_kind, rts_otw **out);
+int rts_otw_destroy(rts_otw *h);
+/* Back to the freshly-constructed state (all streams). */
+int rts_otw_reset(rts_otw *h, void *stream);
+
+/* Whole live sequences, one launch.  `live_dev`: [B][T_max][F] (dtype `live_dtype`, frame-major);
+ * `live_len_dev`: int32[B] valid frames per stream (<= T_max).  Resets the handle, then behaves like
+ * the harness loop `for i in range(T): if ln.insert(live[:, i]) == "stop": break`
+ * (RTS_MODE_INSERT_LOOP) or like `ln.set_live(live)` (RTS_MODE_SET_LIVE).  The live buffer is read
+ * in place and must stay valid until the stream has finished. */
+int rts_otw_run(rts_otw *h, const void *live_dev, int live_dtype, int T_max, const int32_t *live_len_dev,
+                int mode, void *stream);
+
+/* One new frame per stream: replaces insert(live_sample) (otw_eran.py:38-85, livenote_v2.py:43-104).
+ * `frames_dev`: [B][F].  `active_dev`: optional uint8[B]; streams with 0 receive no frame (NULL = all).
+ * Frames are appended to a handle-owned history of 2N frames per stream (the reference's
+ * pre-allocated self.live, otw_eran.py:14,20). */
+int rts_otw_insert(rts_otw *h, const void *frames_dev, int frames_dtype, const uint8_t *active_dev,
+                   void *stream);
+
+/* Getters (synchronise `stream`). */
+int rts_otw_read_state(rts_otw *h, int b, int32_t *state /* RTS_STATE_LEN */, void *stream);
+int rts_otw_read_states(rts_otw *h, int32_t *states /* [B][RTS_STATE_LEN] */, void *stream);
+/* .path: (live_idx, ref_idx) int32 pairs in recording order.  `cap_pairs` = capacity of `pairs`;
+ * *n receives the full length (copy is truncated to cap_pairs). */
+int rts_otw_read_path(rts_otw *h, int b, int32_t *pairs, int cap_pairs, int *n, void *stream);
+/* The live part of .acc_cost: row t over columns [j-c, j] and column j over rows [t-c, t]
+ * (c+1 doubles each, index i <-> offset i-c; NaN where the index is negative). */
+int rts_otw_read_bands(rts_otw *h, int b, double *row_band, double *col_band, void *stream);
+/* Device-side views for zero-copy consumers (torch): path buffer [B][path_cap][2] int32 and state
+ * [B][RTS_STATE_LEN] int32. */
+int rts_otw_device_views(rts_otw *h, int32_t **path_dev, int *path_cap, int32_t **state_dev);
+/* Tuning knob, not semantics: waves per stream workgroup (1, 2, 4 or 8).  Results are identical. */
+int rts_otw_set_waves(rts_otw *h, int waves);
+/* Average device time of the last kernel launches is measured by the caller with HIP events on
+ * `stream`; this returns the kernel's name as it appears in rocprofv3 traces. */
+const char *rts_otw_kernel_name(const rts_otw *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTSYNC_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of librtsync.so (include/rtsync.h).  No fallback: if the HIP library is missing
+or fails to load, importing this module raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "librtsync.so")
+
+# constants mirrored from include/rtsync.h
+F32, F64 = 0, 1
+VARIANT_OTW, VARIANT_LIVENOTE, VARIANT_LIVENOTE_V2 = 0, 1, 2
+COST_DOT, COST_EUCLID = 0, 1
+DIR_NONE, DIR_BOTH, DIR_ROW, DIR_COLUMN = -1, 0, 1, 2
+RUNNING, STOP_REF_END, LIVE_OVERFLOW = 0, 1, 2
+MODE_INSERT_LOOP, MODE_SET_LIVE = 0, 1
+STATE_LEN = 16
+(ST_T, ST_J, ST_DIRECTION, ST_PREVIOUS, ST_RUN_COUNT, ST_STATUS, ST_FIRST_INSERT, ST_N_PATH, ST_CONSUMED,
+ ST_ROW_STRIPS, ST_COL_STRIPS, ST_CELLS_LO, ST_CELLS_HI, ST_PATH_TRUNCATED) = range(14)
+
+# every symbol include/rtsync.h declares (tests/test_abi.py checks the library exports them all)
+EXPORTS = {}
+
+
+class RtsyncError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "librtsync.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python real_time_audio_sync_amd/_build.py`. There is no CPU fallback." % SO_PATH)
+    return ctypes.CDLL(SO_PATH)
+
+
+lib = _load()
+
+_vp, _i32, _pi32 = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)
+
+
+def _decl(name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    EXPORTS[name] = fn
+    return fn
+
+
+_decl("rts_last_error", ctypes.c_char_p, [])
+_decl("rts_version", _i32, [])
+_decl("rts_device_count", _i32, [])
+_decl("rts_otw_create", _i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, ctypes.POINTER(_vp)])
+_decl("rts_otw_destroy", _i32, [_vp])
+_decl("rts_otw_reset", _i32, [_vp, _vp])
+_decl("rts_otw_run", _i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp])
+_decl("rts_otw_insert", _i32, [_vp, _vp, _i32, _vp, _vp])
+_decl("rts_otw_read_state", _i32, [_vp, _i32, _vp, _vp])
+_decl("rts_otw_read_states", _i32, [_vp, _vp, _vp])
+_decl("rts_otw_read_path", _i32, [_vp, _i32, _vp, _i32, _pi32, _vp])
+_decl("rts_otw_read_bands", _i32, [_vp, _i32, _vp, _vp, _vp])
+_decl("rts_otw_device_views", _i32, [_vp, ctypes.POINTER(_vp), _pi32, ctypes.POINTER(_vp)])
+_decl("rts_otw_set_waves", _i32, [_vp, _i32])
+_decl("rts_otw_kernel_name", ctypes.c_char_p, [_vp])
+
+
+def check(rc):
+    if rc != 0:
+        raise RtsyncError("rtsync error %d: %s" % (rc, lib.rts_last_error().decode("utf-8", "replace")))
+    return rc
