@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         // -- corner fix-up + decide (wave 0)
         if (wave == 0) {
             if (lane == 0) {
-                apply_pending();
+                if (!stop) apply_pending();  // livenote_v2.py:139-142 breaks before the update
                 if (do_row) {
                     S.rows += 1;
                     S.cells += nr;
