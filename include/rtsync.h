@@ -21,6 +21,7 @@
 #ifndef RTSYNC_H
 #define RTSYNC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -130,6 +131,25 @@ int rts_otw_set_waves(rts_otw *h, int waves);
 /* Average device time of the last kernel launches is measured by the caller with HIP events on
  * `stream`; this returns the kernel's name as it appears in rocprofv3 traces. */
 const char *rts_otw_kernel_name(const rts_otw *h);
+
+/* ------------------------------------------------------------------------------------------
+ * Offline DTW, batched over B independent (a, b) pairs.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Bytes of the int8 back-pointer workspace rts_dtw needs (B*M*N). */
+int rts_dtw_workspace_bytes(int M, int N, int B, size_t *back_bytes);
+
+/* Replaces dtw.DTW(seq_a, seq_b) -> (cost, acc_cost, path) (dtw.py:5-53).
+ *   a_dev: [B][M][F] frames of seq_a (rows of the matrices), `a_stride` = frames between
+ *          consecutive pairs (0 = every pair shares one a); b_dev / b_stride likewise, [B][N][F].
+ *   cost_dev, acc_dev: double [B][M][N] outputs (dtw.py:11, :14); back_dev: int8 [B][M][N]
+ *          step codes 0 = (0,-1), 1 = (-1,0), 2 = (-1,-1) (dtw.py:30); path_dev: int32
+ *          [B][M+N][2], pairs (i, j) from (0,0) to (M-1,N-1); path_len_dev: int32 [B].
+ * M is limited to 6400 rows (three float64 diagonals are kept in LDS).  Asynchronous on `stream`;
+ * no allocation, no synchronisation (graph-capturable). */
+int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_dev, int b_dtype,
+            long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
+            int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,78 @@
+"""The drop-in classes, used exactly like the reference's harnesses use theirs
+(test_simple.py:101-162, tests.py:143-172), against the golden vectors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def test_otw_insert_loop_like_test_simple(otw_golden, capsys):
+    from real_time_audio_sync_amd.otw_eran import OnlineTimeWarping
+    g = otw_golden
+    ref_seq, live_seq = g["G/ref"], g["G/live"]
+    otw_params = {'c': 50, 'max_run_count': 3}
+    otw2 = OnlineTimeWarping(ref_seq, otw_params)
+    for i in range(live_seq.shape[1]):
+        cont = otw2.insert(live_seq[:, i])
+        if cont == "stop":
+            break
+    path = otw2.path
+    assert isinstance(path, list) and isinstance(path[0], tuple)
+    assert np.array_equal(np.array(path), g["G_otw_c50_insert/path"])
+    assert (otw2.t, otw2.j) == (int(g["G_otw_c50_insert/t"]), int(g["G_otw_c50_insert/j"]))
+    assert otw2.direction in ("Both", "Row", "Column")
+
+
+def test_otw_stop_and_message(otw_golden, capsys):
+    from real_time_audio_sync_amd.otw_eran import OnlineTimeWarping
+    g = otw_golden
+    o = OnlineTimeWarping(g["F/ref"].astype(np.float64), {'c': 20, 'max_run_count': 3})
+    live = g["F/live"].astype(np.float64)
+    n = 0
+    for i in range(live.shape[1]):
+        n += 1
+        if o.insert(live[:, i]) == "stop":
+            break
+    assert n == int(g["F_otw_stop_c20_insert/consumed"])
+    assert "Ran out of ref-sequence" in capsys.readouterr().out
+    assert o.insert(live[:, 0]) == "stop"  # sticky
+    assert np.array_equal(np.array(o.path), g["F_otw_stop_c20_insert/path"])
+
+
+def test_otw_set_live_returns_array(otw_golden):
+    from real_time_audio_sync_amd.otw_eran import OnlineTimeWarping
+    g = otw_golden
+    o = OnlineTimeWarping(g["A/ref"].astype(np.float64), {'c': 10, 'max_run_count': 3})
+    o.set_live(g["A/live"].astype(np.float64))
+    assert isinstance(o.path, np.ndarray) and np.array_equal(o.path, g["A_otw_c10_set_live/path"])
+
+
+def test_livenote_and_v2(otw_golden):
+    from real_time_audio_sync_amd.livenote import LiveNote
+    from real_time_audio_sync_amd.livenote_v2 import LiveNoteV2
+    g = otw_golden
+    params = {'search_band_width': 50, 'max_run_count': 3}
+    debug_params = {'seq': False, 'all': False}
+    ref, live = g["A/ref"].astype(np.float64), g["A/live"].astype(np.float64)
+    ln = LiveNote(ref, params, debug_params)
+    for i in range(live.shape[1]):
+        if ln.insert(live[:, i]) == "stop":
+            break
+    assert np.array_equal(np.array(ln.path), g["A_livenote_c50_insert/path"])
+    assert (ln.live_ptr, ln.ref_ptr) == (int(g["A_livenote_c50_insert/t"]), int(g["A_livenote_c50_insert/j"]))
+    assert ln.direction in ("both", "row", "column")
+    v2 = LiveNoteV2(g["C/ref"].astype(np.float64), params, debug_params, chroma_diff=True)  # tests.py:156
+    lc = g["C/live"].astype(np.float64)
+    for i in range(lc.shape[1]):
+        if v2.insert(lc[:, i]) == "stop":
+            break
+    assert np.array_equal(np.array(v2.path), g["C_livenote_v2_euclid_c50_insert/path"])
+    with pytest.raises(NotImplementedError):
+        v2.acc_cost
