@@ -151,6 +151,84 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
             long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
             int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Chroma front end: frame -> window -> rFFT -> power -> 12-bin filterbank -> L2 normalise.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rts_chroma rts_chroma;
+
+/* num_hops of chroma.create_stft (chroma.py:49-54): floor((n_samples + pad_left - fft_len) / hop) + 1,
+ * 0 if the (padded) signal is shorter than one frame. */
+long long rts_chroma_num_frames(long long n_samples, int fft_len, int hop, int pad_left);
+
+/* A plan = window + twiddles + filterbank on the device.  `fb_host`: 12 x (fft_len/2+1) doubles, row
+ * = pitch class (what librosa.filters.chroma(fs, fft_len) returns at chroma.py:69 / wtw.py:39);
+ * `window_host`: fft_len doubles or NULL for np.hanning(fft_len) (chroma.py:39,:62).  fft_len: power
+ * of two in [64, 4096] (the reference uses 4096, chroma.py:20). */
+int rts_chroma_create(int fft_len, int hop, const double *window_host, const double *fb_host, rts_chroma **out);
+int rts_chroma_destroy(rts_chroma *h);
+
+/* Replaces create_stft + create_chroma (chroma.py:44-75), wav_to_chroma_col (chroma.py:35-42) and the
+ * per-hop chroma of WTW.insert (wtw.py:81-90).  Frame m covers samples [m*hop - pad_left, +fft_len),
+ * indices < 0 read as zero (pad_left = fft_len/2 for create_stft's centred framing, 0 for live
+ * buffers).  `chroma_out_dev`: [n_frames][12] (out_dtype) or NULL; `stft_out_dev`: optional
+ * [n_frames][fft_len/2+1] complex doubles (re, im) -- create_stft's return value, frame-major.
+ * normalize = 0 gives create_chroma(ft, normalize=False). */
+int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, long long n_samples,
+                      int pad_left, int n_frames, int normalize, void *chroma_out_dev, int out_dtype,
+                      double *stft_out_dev, void *stream);
+
+/* create_chroma(ft) for a power spectrum that is already on the device: spec_dev [n_frames][fft_len/2+1]. */
+int rts_chroma_project(rts_chroma *h, const double *spec_dev, int n_frames, int normalize, void *chroma_out_dev,
+                       int out_dtype, void *stream);
+
+/* wav_to_chroma_diff's last step (chroma.py:85-90): out[m][f] = max(chroma[m+1][f] - chroma[m][f], 0),
+ * out has n_frames-1 frames. */
+int rts_chroma_diff(const void *chroma_dev, int dtype, int n_frames, void *out_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Windowed time warping, batched over B live streams against one reference chroma.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rts_wtw rts_wtw;
+
+/* layout of the int32 WTW state vector (8 entries per stream) */
+#define RTS_WTW_STATE_LEN 8
+#define RTS_WTW_ST_CHROMA_PTR 0
+#define RTS_WTW_ST_LIVE_PTR 1
+#define RTS_WTW_ST_REF_PTR 2
+#define RTS_WTW_ST_STATUS 3
+#define RTS_WTW_ST_N_PATH 4
+#define RTS_WTW_ST_N_WINDOWS 5
+#define RTS_WTW_ST_CELLS_LO 6
+#define RTS_WTW_ST_CELLS_HI 7
+
+/* Replaces the chroma-level state of WTW.__init__ (wtw.py:50-68): `chroma_ref_dev` is the reference
+ * chroma [M][F] float64 (what wtw.py:37-41 computes; use rts_chroma_frames with pad_left =
+ * fft_len/2), held by reference.  win_frames = dtw_win_size / hop_size, hop_frames = dtw_hop_size /
+ * hop_size (wtw.py:100,:107), 1 <= win_frames <= 512, hop_frames >= 1.  The handle owns a live
+ * chroma history of 2M frames per stream (wtw.py:52,:55).  keep_last_d != 0 also keeps the last
+ * window's accumulated-cost matrix D for inspection (the reference stores it into self.acc_cost,
+ * wtw.py:105). */
+int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_frames, int hop_frames,
+                   int keep_last_d, rts_wtw **out);
+int rts_wtw_destroy(rts_wtw *h);
+int rts_wtw_reset(rts_wtw *h, void *stream);
+
+/* Replaces the part of WTW.insert below the per-hop chroma (wtw.py:92-128): appends n_new[b] (or
+ * n_max when n_new_dev is NULL) already-normalised live chroma columns per stream -- cols_dev is
+ * [B][n_max][F] -- then, column by column, applies the boundary check (wtw.py:96-97) and runs every
+ * window that has become available (get_cost_matrix, run_dtw, find_path, hand-over).  precheck != 0
+ * first applies insert()'s entry check (wtw.py:76-77).  Status STOP_REF_END replaces the "stop"
+ * return value and is sticky.  Asynchronous on `stream`. */
+int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, const int32_t *n_new_dev,
+                 int precheck, void *stream);
+
+int rts_wtw_read_states(rts_wtw *h, int32_t *states /* [B][RTS_WTW_STATE_LEN] */, void *stream);
+int rts_wtw_read_path(rts_wtw *h, int b, int32_t *pairs, int cap_pairs, int *n, void *stream);
+/* The last window's accumulated-cost matrix D, [W][W] doubles (needs keep_last_d). */
+int rts_wtw_read_last_d(rts_wtw *h, int b, double *d_host, void *stream);
+/* Device views: live chroma history [B][2M][F] float64 and (if kept) the last window's D [B][W][W]. */
+int rts_wtw_device_views(rts_wtw *h, double **live_chroma_dev, int *live_capacity, double **last_d_dev);
+
 #ifdef __cplusplus
 }
 #endif

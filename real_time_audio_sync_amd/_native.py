@@ -66,6 +66,25 @@ _decl("rts_dtw_workspace_bytes", _i32, [_i32, _i32, _i32, ctypes.POINTER(ctypes.
 _decl("rts_dtw", _i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp])
 
 
+_decl("rts_chroma_num_frames", _i64, [_i64, _i32, _i32, _i32])
+_decl("rts_chroma_create", _i32, [_i32, _i32, _vp, _vp, ctypes.POINTER(_vp)])
+_decl("rts_chroma_destroy", _i32, [_vp])
+_decl("rts_chroma_frames", _i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp])
+_decl("rts_chroma_project", _i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp])
+_decl("rts_chroma_diff", _i32, [_vp, _i32, _i32, _vp, _vp])
+
+
+_decl("rts_wtw_create", _i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, ctypes.POINTER(_vp)])
+_decl("rts_wtw_destroy", _i32, [_vp])
+_decl("rts_wtw_reset", _i32, [_vp, _vp])
+_decl("rts_wtw_push", _i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp])
+_decl("rts_wtw_read_states", _i32, [_vp, _vp, _vp])
+_decl("rts_wtw_read_path", _i32, [_vp, _i32, _vp, _i32, _pi32, _vp])
+_decl("rts_wtw_read_last_d", _i32, [_vp, _i32, _vp, _vp])
+_decl("rts_wtw_device_views", _i32, [_vp, ctypes.POINTER(_vp), _pi32, ctypes.POINTER(_vp)])
+WTW_STATE_LEN = 8
+
+
 def check(rc):
     if rc != 0:
         raise RtsyncError("rtsync error %d: %s" % (rc, lib.rts_last_error().decode("utf-8", "replace")))

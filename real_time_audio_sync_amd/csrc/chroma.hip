@@ -1,0 +1,353 @@
+// Chroma front end for gfx950: frame -> Hann -> real FFT -> |.|^2 -> 12-bin filterbank -> L2 normalise.
+//
+// Reference: /root/reference/chroma.py:35-90 (create_stft, create_chroma, wav_to_chroma_col,
+// wav_to_chroma_diff) and the per-hop half of wtw.WTW (wtw.py:37-41, :81-90).
+//
+//   chroma_frames_kernel   one workgroup (256 threads) per frame, persistent over frames:
+//       1. L samples (zero-padded on the left by `pad_left`, chroma.py:49) x window -> LDS as L/2
+//          packed complex float64 (even sample = re, odd = im);
+//       2. L/2-point complex Stockham radix-2 FFT in LDS (float64; twiddles exp(-2 pi i n / L),
+//          n < L/2, are tabulated once per workgroup in LDS from a host-computed table);
+//       3. real-FFT untangling -> the L/2+1 rfft bins, optionally stored (create_stft's output),
+//          power spectrum -> LDS;
+//       4. projection onto the 12 x (L/2+1) filterbank: each thread owns bins k = tid (mod 256)
+//          with 12 running sums, a cross-wave LDS reduction finishes them (a 12-row GEMV per
+//          frame: MFMA would run at the fp64 vector rate with 3/4 of a 16-wide tile empty, so a
+//          plain reduction it is);
+//       5. column L2 normalisation with librosa's tiny-norm rule (chroma.py:74).
+//   chroma_project_kernel  steps 4-5 from a power spectrum already in HBM (create_chroma(ft)).
+//   chroma_diff_kernel     clip(diff(chroma), 0, inf)  (chroma.py:85-90).
+//
+// float64 throughout: the reference computes in float64 and the alignment paths downstream must
+// not move.  numpy's pocketfft orders its additions differently, so chroma values agree with the
+// oracle to ~1e-13 relative, not bitwise (tolerance stated in tests/test_chroma_gpu.py).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace rts {
+
+constexpr int kCh = 12;
+constexpr int kChromaNT = 256;
+
+struct ChromaArgs {
+    const void *samples;     // [n_samples]
+    const double *window;    // [L]
+    const double2 *twiddle;  // [L/2]  exp(-2 pi i n / L)
+    const double *fb;        // [12][L/2+1]
+    void *chroma_out;        // [n_frames][12]
+    double2 *stft_out;       // [n_frames][L/2+1] or NULL
+    const double *spec_in;   // projection-only entry: [n_frames][L/2+1]
+    long long n_samples;
+    long long frame_offset;  // sample index of frame 0, element 0 (= -pad_left)
+    int L, logL2, hop, n_frames, normalize, samples_f64, out_f64;
+};
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// Steps 4-5 for one frame whose power spectrum sits in LDS.  `red` = LDS scratch [12][4] doubles.
+__device__ __forceinline__ void project_normalize(const ChromaArgs &g, const double *spec, double *red, int frame,
+                                                  int tid) {
+    const int nb = g.L / 2 + 1;
+    double acc[kCh];
+#pragma unroll
+    for (int p = 0; p < kCh; p++) acc[p] = 0.0;
+    for (int k = tid; k < nb; k += kChromaNT) {
+        const double s = spec[k];
+#pragma unroll
+        for (int p = 0; p < kCh; p++) acc[p] = fma(g.fb[(size_t)p * nb + k], s, acc[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < kCh; p++) {
+        double v = acc[p];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[p * 4 + (tid >> 6)] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double c[kCh];
+        double ss = 0.0;
+#pragma unroll
+        for (int p = 0; p < kCh; p++) {
+            c[p] = ((red[p * 4 + 0] + red[p * 4 + 1]) + (red[p * 4 + 2] + red[p * 4 + 3]));
+            const double sq = c[p] * c[p];
+            ss = ss + sq;
+        }
+        double len = sqrt(ss);
+        if (!g.normalize || len < 2.2250738585072014e-308) len = 1.0;  // librosa.util.normalize, fill=None
+#pragma unroll
+        for (int p = 0; p < kCh; p++) {
+            const double v = c[p] / len;
+            if (g.out_f64)
+                reinterpret_cast<double *>(g.chroma_out)[(size_t)frame * kCh + p] = v;
+            else
+                reinterpret_cast<float *>(g.chroma_out)[(size_t)frame * kCh + p] = (float)v;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) {
+    extern __shared__ __align__(16) unsigned char ch_smem[];
+    const int L = g.L, N2 = L / 2;
+    double2 *z = reinterpret_cast<double2 *>(ch_smem);  // [N2]
+    double2 *tw = z + N2;                               // [N2]
+    double *spec = reinterpret_cast<double *>(tw + N2); // [N2 + 1]
+    double *red = spec + (N2 + 2);                      // [48]
+    const int tid = threadIdx.x;
+
+    for (int n = tid; n < N2; n += kChromaNT) tw[n] = g.twiddle[n];
+    __syncthreads();
+
+    for (int frame = blockIdx.x; frame < g.n_frames; frame += gridDim.x) {
+        // 1. load + window, packed as complex
+        const long long s0 = g.frame_offset + (long long)frame * g.hop;
+        for (int n = tid; n < N2; n += kChromaNT) {
+            const long long s = s0 + 2 * n;
+            double x0 = 0.0, x1 = 0.0;
+            if (s >= 0 && s < g.n_samples)
+                x0 = g.samples_f64 ? reinterpret_cast<const double *>(g.samples)[s]
+                                   : (double)reinterpret_cast<const float *>(g.samples)[s];
+            if (s + 1 >= 0 && s + 1 < g.n_samples)
+                x1 = g.samples_f64 ? reinterpret_cast<const double *>(g.samples)[s + 1]
+                                   : (double)reinterpret_cast<const float *>(g.samples)[s + 1];
+            z[n] = make_double2(x0 * g.window[2 * n], x1 * g.window[2 * n + 1]);
+        }
+        __syncthreads();
+        // 2. Stockham radix-2, N2 points, in place via registers (read all, barrier, write all)
+        const int half = N2 / 2;
+        constexpr int kMaxBf = 4;  // butterflies per thread per stage (N2/2/256 <= 4 for L <= 4096)
+        for (int p = 1; p < N2; p <<= 1) {
+            double2 o0[kMaxBf], o1[kMaxBf];
+            int jj[kMaxBf];
+            const int tstride = N2 / p;  // twiddle index step: exp(-2 pi i k / (2p)) = tw[k * (L/2) / p ... ]
+#pragma unroll
+            for (int r = 0; r < kMaxBf; r++) {
+                const int i = tid + r * kChromaNT;
+                if (i < half) {
+                    const int k = i & (p - 1);
+                    const double2 u0 = z[i];
+                    const double2 u1 = cmul(tw[k * tstride], z[i + half]);
+                    o0[r] = make_double2(u0.x + u1.x, u0.y + u1.y);
+                    o1[r] = make_double2(u0.x - u1.x, u0.y - u1.y);
+                    jj[r] = ((i - k) << 1) + k;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kMaxBf; r++) {
+                const int i = tid + r * kChromaNT;
+                if (i < half) {
+                    z[jj[r]] = o0[r];
+                    z[jj[r] + p] = o1[r];
+                }
+            }
+            __syncthreads();
+        }
+        // 3. untangle: X[k] = E[k] + W_L^k O[k], E = (Z[k] + conj Z[N2-k]) / 2, O = (Z[k] - conj Z[N2-k]) / (2i)
+        const int nb = N2 + 1;
+        for (int k = tid; k < nb; k += kChromaNT) {
+            const double2 a = z[k & (N2 - 1)];          // Z[N2] == Z[0]
+            const double2 bq = z[(N2 - k) & (N2 - 1)];
+            const double2 b = make_double2(bq.x, -bq.y);  // conj
+            const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+            const double2 dm = make_double2(a.x - b.x, a.y - b.y);
+            const double2 o = make_double2(0.5 * dm.y, -0.5 * dm.x);  // dm / (2i)
+            const double2 w = (k < N2) ? tw[k] : make_double2(-1.0, 0.0);
+            const double2 wo = cmul(w, o);
+            const double2 x = make_double2(e.x + wo.x, e.y + wo.y);
+            if (g.stft_out) g.stft_out[(size_t)frame * nb + k] = x;
+            spec[k] = x.x * x.x + x.y * x.y;
+        }
+        __syncthreads();
+        // 4-5
+        if (g.chroma_out) project_normalize(g, spec, red, frame, tid);
+        else __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kChromaNT) chroma_project_kernel(ChromaArgs g) {
+    extern __shared__ __align__(16) unsigned char ch_smem[];
+    const int nb = g.L / 2 + 1;
+    double *spec = reinterpret_cast<double *>(ch_smem);
+    double *red = spec + (nb + 1);
+    const int tid = threadIdx.x;
+    for (int frame = blockIdx.x; frame < g.n_frames; frame += gridDim.x) {
+        for (int k = tid; k < nb; k += kChromaNT) spec[k] = g.spec_in[(size_t)frame * nb + k];
+        __syncthreads();
+        project_normalize(g, spec, red, frame, tid);
+    }
+}
+
+// out[m][f] = max(in[m+1][f] - in[m][f], 0), m < n_frames - 1   (np.clip(np.diff(chroma), 0, inf))
+__global__ void chroma_diff_kernel(const void *in, void *out, long long n_out, int f64) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    if (f64) {
+        const double *x = reinterpret_cast<const double *>(in);
+        const double d = x[i + kCh] - x[i];
+        reinterpret_cast<double *>(out)[i] = d > 0.0 ? d : 0.0;
+    } else {
+        const float *x = reinterpret_cast<const float *>(in);
+        const float d = x[i + kCh] - x[i];
+        reinterpret_cast<float *>(out)[i] = d > 0.0f ? d : 0.0f;
+    }
+}
+
+}  // namespace rts
+
+struct rts_chroma {
+    int L, hop, logL2;
+    double *window;    // device [L]
+    double2 *twiddle;  // device [L/2]
+    double *fb;        // device [12][L/2+1]
+    size_t smem_frames, smem_project;
+};
+
+extern "C" {
+
+long long rts_chroma_num_frames(long long n_samples, int fft_len, int hop, int pad_left) {
+    const long long n = n_samples + pad_left;  // chroma.py:49-54
+    if (fft_len < 2 || hop < 1 || n < fft_len) return 0;
+    return (n - fft_len) / hop + 1;
+}
+
+int rts_chroma_create(int fft_len, int hop, const double *window_host, const double *fb_host, rts_chroma **out) {
+    using namespace rts;
+    if (!out) return set_error(RTS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!fb_host) return set_error(RTS_ERR_INVALID, "fb_host is NULL (12 x (fft_len/2+1) filterbank)");
+    if (fft_len < 64 || fft_len > 4096 || (fft_len & (fft_len - 1)))
+        return set_error(RTS_ERR_UNSUPPORTED, "fft_len must be a power of two in [64, 4096] (got %d)", fft_len);
+    if (hop < 1) return set_error(RTS_ERR_INVALID, "hop must be >= 1");
+    rts_chroma *h = (rts_chroma *)calloc(1, sizeof(rts_chroma));
+    if (!h) return set_error(RTS_ERR_INVALID, "out of host memory");
+    h->L = fft_len;
+    h->hop = hop;
+    const int L = fft_len, N2 = L / 2, nb = N2 + 1;
+    double *win = (double *)malloc(sizeof(double) * L);
+    double2 *tw = (double2 *)malloc(sizeof(double2) * N2);
+    if (window_host) {
+        memcpy(win, window_host, sizeof(double) * L);
+    } else {  // np.hanning(L): 0.5 + 0.5 cos(pi n / (L-1)), n = 1-L, 3-L, ..., L-1
+        for (int i = 0; i < L; i++) win[i] = 0.5 + 0.5 * cos(M_PI * (double)(2 * i + 1 - L) / (double)(L - 1));
+    }
+    for (int n = 0; n < N2; n++) {
+        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)n / (long double)L;
+        tw[n].x = (double)cosl(ang);
+        tw[n].y = (double)sinl(ang);
+    }
+    hipError_t e;
+    if ((e = hipMalloc((void **)&h->window, sizeof(double) * L)) != hipSuccess ||
+        (e = hipMalloc((void **)&h->twiddle, sizeof(double2) * N2)) != hipSuccess ||
+        (e = hipMalloc((void **)&h->fb, sizeof(double) * kCh * nb)) != hipSuccess ||
+        (e = hipMemcpy(h->window, win, sizeof(double) * L, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(h->twiddle, tw, sizeof(double2) * N2, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(h->fb, fb_host, sizeof(double) * kCh * nb, hipMemcpyHostToDevice)) != hipSuccess) {
+        free(win);
+        free(tw);
+        rts_chroma_destroy(h);
+        return set_error(RTS_ERR_HIP, "chroma plan upload failed: %s", hipGetErrorString(e));
+    }
+    free(win);
+    free(tw);
+    h->smem_frames = sizeof(double2) * 2 * N2 + sizeof(double) * (N2 + 2 + 48);
+    h->smem_project = sizeof(double) * (nb + 1 + 48);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        rts_chroma_destroy(h);
+        return set_error(RTS_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return RTS_OK;
+}
+
+int rts_chroma_destroy(rts_chroma *h) {
+    if (!h) return RTS_OK;
+    if (h->window) (void)hipFree(h->window);
+    if (h->twiddle) (void)hipFree(h->twiddle);
+    if (h->fb) (void)hipFree(h->fb);
+    free(h);
+    return RTS_OK;
+}
+
+int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, long long n_samples,
+                      int pad_left, int n_frames, int normalize, void *chroma_out_dev, int out_dtype,
+                      double *stft_out_dev, void *stream) {
+    using namespace rts;
+    if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (!samples_dev) return set_error(RTS_ERR_INVALID, "samples_dev is NULL");
+    if (!chroma_out_dev && !stft_out_dev) return set_error(RTS_ERR_INVALID, "no output requested");
+    if ((sample_dtype != RTS_F32 && sample_dtype != RTS_F64) || (out_dtype != RTS_F32 && out_dtype != RTS_F64))
+        return set_error(RTS_ERR_INVALID, "bad dtype");
+    if (n_frames < 0 || pad_left < 0 || n_samples < 0) return set_error(RTS_ERR_INVALID, "negative size");
+    if ((long long)n_frames > rts_chroma_num_frames(n_samples, h->L, h->hop, pad_left))
+        return set_error(RTS_ERR_INVALID, "n_frames=%d exceeds the %lld full frames in %lld samples", n_frames,
+                         rts_chroma_num_frames(n_samples, h->L, h->hop, pad_left), n_samples);
+    if (n_frames == 0) return RTS_OK;
+    ChromaArgs g;
+    memset(&g, 0, sizeof(g));
+    g.samples = samples_dev;
+    g.window = h->window;
+    g.twiddle = h->twiddle;
+    g.fb = h->fb;
+    g.chroma_out = chroma_out_dev;
+    g.stft_out = reinterpret_cast<double2 *>(stft_out_dev);
+    g.n_samples = n_samples;
+    g.frame_offset = -(long long)pad_left;
+    g.L = h->L;
+    g.hop = h->hop;
+    g.n_frames = n_frames;
+    g.normalize = normalize;
+    g.samples_f64 = sample_dtype == RTS_F64;
+    g.out_f64 = out_dtype == RTS_F64;
+    const int grid = n_frames < 512 ? n_frames : 512;
+    hipLaunchKernelGGL(chroma_frames_kernel, dim3(grid), dim3(kChromaNT), h->smem_frames, (hipStream_t)stream, g);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
+int rts_chroma_project(rts_chroma *h, const double *spec_dev, int n_frames, int normalize, void *chroma_out_dev,
+                       int out_dtype, void *stream) {
+    using namespace rts;
+    if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (!spec_dev || !chroma_out_dev) return set_error(RTS_ERR_INVALID, "NULL device buffer");
+    if (out_dtype != RTS_F32 && out_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad dtype");
+    if (n_frames < 0) return set_error(RTS_ERR_INVALID, "negative size");
+    if (n_frames == 0) return RTS_OK;
+    ChromaArgs g;
+    memset(&g, 0, sizeof(g));
+    g.fb = h->fb;
+    g.spec_in = spec_dev;
+    g.chroma_out = chroma_out_dev;
+    g.L = h->L;
+    g.n_frames = n_frames;
+    g.normalize = normalize;
+    g.out_f64 = out_dtype == RTS_F64;
+    const int grid = n_frames < 1024 ? n_frames : 1024;
+    hipLaunchKernelGGL(chroma_project_kernel, dim3(grid), dim3(kChromaNT), h->smem_project, (hipStream_t)stream, g);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
+int rts_chroma_diff(const void *chroma_dev, int dtype, int n_frames, void *out_dev, void *stream) {
+    using namespace rts;
+    if (!chroma_dev || !out_dev) return set_error(RTS_ERR_INVALID, "NULL device buffer");
+    if (dtype != RTS_F32 && dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad dtype");
+    if (n_frames < 2) return RTS_OK;
+    const long long n_out = (long long)(n_frames - 1) * kCh;
+    hipLaunchKernelGGL(chroma_diff_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       chroma_dev, out_dev, n_out, dtype == RTS_F64);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,425 @@
+// Windowed time warping for gfx950: the chroma-level half of wtw.WTW.insert
+// (/root/reference/wtw.py:92-128) with get_cost_matrix (:162-171), run_dtw (:173-217) and
+// find_path (:219-240), batched over B independent live streams against one reference chroma.
+//
+// One workgroup per stream walks its newly appended live chroma columns; whenever a full window
+// of W live frames is available it
+//   1. computes the W x W normalised-cosine cost with the reference's dot orders (norms: fma
+//      chain = x.dot(x) on a contiguous copy; cross term: OpenBLAS strided ddot order),
+//   2. sweeps the anti-diagonals of the unit-weight DP (candidates (i-1,j), (i,j-1), (i-1,j-1),
+//      strict '<' in that order, codes 3/1/2) with three rotating float64 diagonals in LDS -- all
+//      cells of a diagonal are independent, so D and B are bit-identical to the serial loops,
+//   3. backtracks B and applies the hand-over rule of wtw.py:107-128 (append sub-path points with
+//      l <= dtw_hop/hop, move (live_ptr, ref_ptr) to the last appended point) on one lane.
+// The back-pointer matrix lives in LDS for W <= 128 and in an HBM workspace above that.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace rts {
+
+constexpr int kWF = 12;
+constexpr int kWtwNT = 256;
+constexpr int kWtwLdsB = 128;  // largest W whose back-pointers stay in LDS
+
+struct WtwArgs {
+    const double *ref;    // [M][F]
+    double *live;         // [B][N][F]  (N = 2M)
+    int32_t *appended;    // [B] columns written to `live` so far
+    int32_t *state;       // [B][8]: chroma_ptr, live_ptr, ref_ptr, status, n_path, n_windows, cells_lo, cells_hi
+    int32_t *path;        // [B][path_cap][2]
+    int8_t *bwork;        // [B][W][W] or NULL when W <= kWtwLdsB
+    double *dlast;        // [B][W][W] last window's D (optional, NULL = not stored)
+    int M, N, W, hopf, path_cap;
+};
+
+__device__ __forceinline__ double wtw_dot_chain(const double *x, const double *y) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < kWF; i++) s = fma(x[i], y[i], s);
+    return s;
+}
+
+__device__ __forceinline__ double wtw_dot_strided(const double *x, const double *y) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < kWF; i += 4) {
+        const double m3 = y[i + 2] * x[i + 2];
+        const double m4 = y[i + 3] * x[i + 3];
+        const double a = fma(y[i], x[i], m3);
+        const double b = fma(y[i + 1], x[i + 1], m4);
+        t1 = t1 + a;
+        t2 = t2 + b;
+    }
+    return t1 + t2;
+}
+
+__global__ void __launch_bounds__(kWtwNT) wtw_advance_kernel(WtwArgs g) {
+    extern __shared__ __align__(16) unsigned char wtw_smem[];
+    const int W = g.W;
+    double *xs = reinterpret_cast<double *>(wtw_smem);  // [W][F] live window
+    double *ys = xs + (size_t)W * kWF;                  // [W][F] ref window
+    double *nx = ys + (size_t)W * kWF;                  // [W]
+    double *ny = nx + W;                                // [W]
+    double *diag = ny + W;                              // [3][W]
+    int32_t *sub = reinterpret_cast<int32_t *>(diag + 3 * (size_t)W);  // [2W][2]
+    int8_t *bl = reinterpret_cast<int8_t *>(sub + 4 * (size_t)W);      // [W][W] when W <= kWtwLdsB
+    __shared__ int s_chroma_ptr, s_live_ptr, s_ref_ptr, s_status, s_n_path, s_n_windows, s_go;
+    __shared__ long long s_cells;
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int32_t *st = g.state + (size_t)b * 8;
+    const double *live = g.live + (size_t)b * g.N * kWF;
+    int8_t *Bm = (W <= kWtwLdsB) ? bl : (g.bwork + (size_t)b * W * W);
+    const int appended = g.appended[b];
+
+    if (tid == 0) {
+        s_chroma_ptr = st[0];
+        s_live_ptr = st[1];
+        s_ref_ptr = st[2];
+        s_status = st[3];
+        s_n_path = st[4];
+        s_n_windows = st[5];
+        s_cells = ((long long)(uint32_t)st[7] << 32) | (uint32_t)st[6];
+    }
+    __syncthreads();
+
+    for (;;) {
+        // ---- one new column (wtw.py:92-97), decided by lane 0, broadcast through s_go
+        if (tid == 0) {
+            int go = 0;
+            if (s_status == RTS_RUNNING && s_chroma_ptr < appended) {
+                s_chroma_ptr += 1;
+                if (s_ref_ptr >= (g.M - 1 - W) || s_live_ptr >= (g.N - 1 - W))
+                    s_status = RTS_STOP_REF_END;
+                else
+                    go = 1;
+            }
+            s_go = go;
+        }
+        __syncthreads();
+        if (!s_go) break;
+        // ---- windows (wtw.py:100-128)
+        while (s_chroma_ptr - s_live_ptr >= W) {  // uniform: shared values only change behind barriers
+            const int lp = s_live_ptr, rp = s_ref_ptr;
+            const int n = W;
+            int m = W;
+            if (rp + m > g.M) m = g.M - rp;  // numpy slice truncation of chroma_ref[:, rp:rp+W]
+            if (m <= 0) break;
+            for (int idx = tid; idx < n * kWF; idx += kWtwNT) xs[idx] = live[(size_t)lp * kWF + idx];
+            for (int idx = tid; idx < m * kWF; idx += kWtwNT) ys[idx] = g.ref[(size_t)rp * kWF + idx];
+            __syncthreads();
+            for (int i = tid; i < n; i += kWtwNT) nx[i] = sqrt(wtw_dot_chain(xs + i * kWF, xs + i * kWF));
+            for (int j = tid; j < m; j += kWtwNT) ny[j] = sqrt(wtw_dot_chain(ys + j * kWF, ys + j * kWF));
+            __syncthreads();
+            const int n_diag = n + m - 1;
+            for (int d = 0; d < n_diag; d++) {
+                double *cur = diag + (size_t)(d % 3) * W;
+                const double *p1 = diag + (size_t)((d + 2) % 3) * W;
+                const double *p2 = diag + (size_t)((d + 1) % 3) * W;
+                for (int i = tid; i < n; i += kWtwNT) {
+                    const int j = d - i;
+                    if (j < 0 || j >= m) continue;
+                    const double dot = wtw_dot_strided(xs + i * kWF, ys + j * kWF);
+                    const double c = 1.0 - dot / (nx[i] * ny[j]);  // wtw.py:169
+                    double dv;
+                    int8_t code;
+                    if (i == 0 && j == 0) {
+                        dv = c;
+                        code = 0;
+                    } else if (j == 0) {
+                        dv = p1[i - 1] + c;  // wtw.py:187-191
+                        code = 3;
+                    } else if (i == 0) {
+                        dv = p1[0] + c;  // wtw.py:194-198
+                        code = 1;
+                    } else {
+                        double mc = p1[i - 1];  // (i-1, j)
+                        code = 3;
+                        const double v1 = p1[i];  // (i, j-1)
+                        if (v1 < mc) {
+                            mc = v1;
+                            code = 1;
+                        }
+                        const double v2 = p2[i - 1];  // (i-1, j-1)
+                        if (v2 < mc) {
+                            mc = v2;
+                            code = 2;
+                        }
+                        dv = mc + c;
+                    }
+                    cur[i] = dv;
+                    Bm[(size_t)i * W + j] = code;
+                    if (g.dlast) g.dlast[((size_t)b * W + i) * W + j] = dv;
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                // find_path (wtw.py:219-240): walk back from (n-1, m-1); sub[] holds it reversed
+                int i = n - 1, j = m - 1, len = 0;
+                sub[0] = i;
+                sub[1] = j;
+                len = 1;
+                while (!(i == 0 && j == 0) && len < 2 * W) {
+                    const int8_t p = Bm[(size_t)i * W + j];
+                    if (p == 1)
+                        j -= 1;
+                    else if (p == 2) {
+                        i -= 1;
+                        j -= 1;
+                    } else
+                        i -= 1;
+                    sub[2 * len] = i;
+                    sub[2 * len + 1] = j;
+                    len++;
+                }
+                // hand-over (wtw.py:107-128), iterating the sub-path forwards
+                int change = 0, idx_l = 0, idx_r = 0;
+                int32_t *path = g.path + (size_t)b * g.path_cap * 2;
+                for (int q = len - 1; q >= 0; q--) {
+                    const int l = sub[2 * q], r = sub[2 * q + 1];
+                    if (l <= g.hopf) {
+                        if (s_n_path < g.path_cap) {
+                            path[2 * s_n_path] = l + lp;
+                            path[2 * s_n_path + 1] = r + rp;
+                        }
+                        s_n_path += 1;
+                        idx_l = l;
+                        idx_r = r;
+                    } else {
+                        change = 1;
+                        break;
+                    }
+                }
+                if (change) {
+                    s_live_ptr = lp + idx_l;
+                    s_ref_ptr = rp + idx_r;
+                } else {
+                    s_live_ptr = lp + g.hopf;
+                    s_ref_ptr = rp + g.hopf;
+                }
+                s_n_windows += 1;
+                s_cells += (long long)n * m;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        st[0] = s_chroma_ptr;
+        st[1] = s_live_ptr;
+        st[2] = s_ref_ptr;
+        st[3] = s_status;
+        st[4] = s_n_path;
+        st[5] = s_n_windows;
+        st[6] = (int32_t)(uint32_t)(s_cells & 0xffffffffLL);
+        st[7] = (int32_t)(uint32_t)((unsigned long long)s_cells >> 32);
+    }
+}
+
+// wtw.py:76-77: the check made at the top of insert(), before any column is processed.
+__global__ void wtw_precheck_kernel(int32_t *state, int B, int M, int N) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int32_t *st = state + (size_t)b * 8;
+    if (st[3] == RTS_RUNNING && (st[2] >= M - 1 || st[1] >= N - 1)) st[3] = RTS_STOP_REF_END;
+}
+
+// Append n_new[b] columns from cols [B][n_max][F] to the live history; columns beyond the 2M capacity
+// are dropped (the reference would raise IndexError) and flagged through status LIVE_OVERFLOW.
+__global__ void wtw_append_kernel(double *live, int32_t *appended, int32_t *state, const void *cols, int cols_f64,
+                                  const int32_t *n_new, int n_uniform, int n_max, int B, int N) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int nn = n_new ? n_new[b] : n_uniform;
+    const int base = appended[b];
+    const int running = state[(size_t)b * 8 + 3] == RTS_RUNNING;
+    __syncthreads();
+    if (!running) return;  // sticky stop: later columns are ignored
+    int take = nn;
+    if (base + take > N) take = N - base > 0 ? N - base : 0;
+    for (int idx = threadIdx.x; idx < take * kWF; idx += blockDim.x) {
+        const size_t src = ((size_t)b * n_max) * kWF + idx;
+        const double v = cols_f64 ? reinterpret_cast<const double *>(cols)[src]
+                                  : (double)reinterpret_cast<const float *>(cols)[src];
+        live[((size_t)b * N + base) * kWF + idx] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        appended[b] = base + take;
+        if (take < nn) state[(size_t)b * 8 + 3] = RTS_LIVE_OVERFLOW;
+    }
+}
+
+}  // namespace rts
+
+struct rts_wtw {
+    const double *ref;
+    int M, N, B, W, hopf, path_cap;
+    double *live;
+    int32_t *appended, *state, *path;
+    int8_t *bwork;
+    double *dlast;
+    size_t smem;
+};
+
+extern "C" {
+
+int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_frames, int hop_frames, int keep_last_d,
+                   rts_wtw **out) {
+    using namespace rts;
+    if (!out) return set_error(RTS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!chroma_ref_dev) return set_error(RTS_ERR_INVALID, "chroma_ref_dev is NULL");
+    if (F != kWF) return set_error(RTS_ERR_UNSUPPORTED, "F must be 12 chroma bins (got %d)", F);
+    if (M < 1 || B < 1) return set_error(RTS_ERR_INVALID, "M and B must be >= 1");
+    if (win_frames < 1) return set_error(RTS_ERR_INVALID, "dtw_win_size / hop_size must be >= 1 frame");
+    if (hop_frames < 1)
+        return set_error(RTS_ERR_INVALID, "dtw_hop_size / hop_size must be >= 1 frame (the reference loops forever at 0)");
+    if (win_frames > 512)
+        return set_error(RTS_ERR_UNSUPPORTED, "window of %d frames exceeds the 512 the single-workgroup DP holds", win_frames);
+    rts_wtw *h = (rts_wtw *)calloc(1, sizeof(rts_wtw));
+    if (!h) return set_error(RTS_ERR_INVALID, "out of host memory");
+    h->ref = chroma_ref_dev;
+    h->M = M;
+    h->N = 2 * M;  // wtw.py:52
+    h->B = B;
+    h->W = win_frames;
+    h->hopf = hop_frames;
+    h->path_cap = (h->N / hop_frames + 2) * (win_frames + hop_frames + 2);
+    const int W = win_frames;
+    h->smem = sizeof(double) * ((size_t)2 * W * kWF + 2 * W + 3 * W) + sizeof(int32_t) * 4 * W +
+              (W <= kWtwLdsB ? (size_t)W * W : 0) + 64;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&h->live, sizeof(double) * kWF * (size_t)h->N * B)) != hipSuccess ||
+        (e = hipMalloc((void **)&h->appended, sizeof(int32_t) * (size_t)B)) != hipSuccess ||
+        (e = hipMalloc((void **)&h->state, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess ||
+        (e = hipMalloc((void **)&h->path, sizeof(int32_t) * 2 * (size_t)h->path_cap * B)) != hipSuccess ||
+        (W > kWtwLdsB && (e = hipMalloc((void **)&h->bwork, (size_t)B * W * W)) != hipSuccess) ||
+        (keep_last_d && (e = hipMalloc((void **)&h->dlast, sizeof(double) * (size_t)B * W * W)) != hipSuccess) ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) {
+        rts_wtw_destroy(h);
+        return set_error(RTS_ERR_HIP, "WTW allocation failed: %s", hipGetErrorString(e));
+    }
+    int rc = rts_wtw_reset(h, nullptr);
+    if (rc != RTS_OK) {
+        rts_wtw_destroy(h);
+        return rc;
+    }
+    RTS_HIP(hipStreamSynchronize(nullptr));
+    *out = h;
+    return RTS_OK;
+}
+
+int rts_wtw_destroy(rts_wtw *h) {
+    if (!h) return RTS_OK;
+    if (h->live) (void)hipFree(h->live);
+    if (h->appended) (void)hipFree(h->appended);
+    if (h->state) (void)hipFree(h->state);
+    if (h->path) (void)hipFree(h->path);
+    if (h->bwork) (void)hipFree(h->bwork);
+    if (h->dlast) (void)hipFree(h->dlast);
+    free(h);
+    return RTS_OK;
+}
+
+int rts_wtw_reset(rts_wtw *h, void *stream) {
+    using namespace rts;
+    if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    RTS_HIP(hipMemsetAsync(h->appended, 0, sizeof(int32_t) * (size_t)h->B, s));
+    RTS_HIP(hipMemsetAsync(h->state, 0, sizeof(int32_t) * 8 * (size_t)h->B, s));
+    // wtw.py:55: chroma_live starts as zeros
+    RTS_HIP(hipMemsetAsync(h->live, 0, sizeof(double) * kWF * (size_t)h->N * h->B, s));
+    return RTS_OK;
+}
+
+int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, const int32_t *n_new_dev, int precheck,
+                 void *stream) {
+    using namespace rts;
+    if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (n_max < 0) return set_error(RTS_ERR_INVALID, "n_max < 0");
+    if (n_max > 0 && !cols_dev) return set_error(RTS_ERR_INVALID, "cols_dev is NULL");
+    if (cols_dtype != RTS_F32 && cols_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad cols_dtype %d", cols_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    if (precheck) {
+        hipLaunchKernelGGL(wtw_precheck_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, h->state, h->B, h->M, h->N);
+        RTS_HIP(hipGetLastError());
+    }
+    if (n_max == 0) return RTS_OK;
+    hipLaunchKernelGGL(wtw_append_kernel, dim3(h->B), dim3(256), 0, s, h->live, h->appended, h->state, cols_dev,
+                       cols_dtype == RTS_F64, n_new_dev, n_max, n_max, h->B, h->N);
+    RTS_HIP(hipGetLastError());
+    WtwArgs g;
+    g.ref = h->ref;
+    g.live = h->live;
+    g.appended = h->appended;
+    g.state = h->state;
+    g.path = h->path;
+    g.bwork = h->bwork;
+    g.dlast = h->dlast;
+    g.M = h->M;
+    g.N = h->N;
+    g.W = h->W;
+    g.hopf = h->hopf;
+    g.path_cap = h->path_cap;
+    hipLaunchKernelGGL(wtw_advance_kernel, dim3(h->B), dim3(kWtwNT), h->smem, s, g);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
+int rts_wtw_read_states(rts_wtw *h, int32_t *states, void *stream) {
+    using namespace rts;
+    if (!h || !states) return set_error(RTS_ERR_INVALID, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    RTS_HIP(hipMemcpyAsync(states, h->state, sizeof(int32_t) * 8 * (size_t)h->B, hipMemcpyDeviceToHost, s));
+    RTS_HIP(hipStreamSynchronize(s));
+    return RTS_OK;
+}
+
+int rts_wtw_read_path(rts_wtw *h, int b, int32_t *pairs, int cap_pairs, int *n, void *stream) {
+    using namespace rts;
+    if (!h || !n) return set_error(RTS_ERR_INVALID, "NULL argument");
+    if (b < 0 || b >= h->B) return set_error(RTS_ERR_INVALID, "stream index %d out of range [0, %d)", b, h->B);
+    hipStream_t s = (hipStream_t)stream;
+    int32_t np = 0;
+    RTS_HIP(hipMemcpyAsync(&np, h->state + (size_t)b * 8 + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    RTS_HIP(hipStreamSynchronize(s));
+    *n = np;
+    int m = np < h->path_cap ? np : h->path_cap;
+    if (m > cap_pairs) m = cap_pairs;
+    if (m > 0 && pairs) {
+        RTS_HIP(hipMemcpyAsync(pairs, h->path + (size_t)b * h->path_cap * 2, sizeof(int32_t) * 2 * (size_t)m,
+                               hipMemcpyDeviceToHost, s));
+        RTS_HIP(hipStreamSynchronize(s));
+    }
+    return RTS_OK;
+}
+
+int rts_wtw_read_last_d(rts_wtw *h, int b, double *d_host, void *stream) {
+    using namespace rts;
+    if (!h || !d_host) return set_error(RTS_ERR_INVALID, "NULL argument");
+    if (b < 0 || b >= h->B) return set_error(RTS_ERR_INVALID, "stream index %d out of range [0, %d)", b, h->B);
+    if (!h->dlast) return set_error(RTS_ERR_INVALID, "handle was created with keep_last_d = 0");
+    hipStream_t s = (hipStream_t)stream;
+    RTS_HIP(hipMemcpyAsync(d_host, h->dlast + (size_t)b * h->W * h->W, sizeof(double) * (size_t)h->W * h->W,
+                           hipMemcpyDeviceToHost, s));
+    RTS_HIP(hipStreamSynchronize(s));
+    return RTS_OK;
+}
+
+int rts_wtw_device_views(rts_wtw *h, double **live_chroma_dev, int *live_capacity, double **last_d_dev) {
+    using namespace rts;
+    if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (live_chroma_dev) *live_chroma_dev = h->live;
+    if (live_capacity) *live_capacity = h->N;
+    if (last_d_dev) *last_d_dev = h->dlast;
+    return RTS_OK;
+}
+
+}  // extern "C"
