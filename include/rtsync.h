@@ -77,6 +77,7 @@ extern "C" {
 #define RTS_ST_CELLS_LO 11    /* cells evaluated, low/high 32 bits */
 #define RTS_ST_CELLS_HI 12
 #define RTS_ST_PATH_TRUNCATED 13
+#define RTS_ST_BAND_RECOMPUTES 15 /* times a band minimum left the window and was recomputed (diagnostic) */
 
 const char *rts_last_error(void);
 int rts_version(void);

@@ -16,6 +16,7 @@ MODE_INSERT_LOOP, MODE_SET_LIVE = 0, 1
 STATE_LEN = 16
 (ST_T, ST_J, ST_DIRECTION, ST_PREVIOUS, ST_RUN_COUNT, ST_STATUS, ST_FIRST_INSERT, ST_N_PATH, ST_CONSUMED,
  ST_ROW_STRIPS, ST_COL_STRIPS, ST_CELLS_LO, ST_CELLS_HI, ST_PATH_TRUNCATED) = range(14)
+ST_BAND_RECOMPUTES = 15
 
 # every symbol include/rtsync.h declares (tests/test_abi.py checks the library exports them all)
 EXPORTS = {}

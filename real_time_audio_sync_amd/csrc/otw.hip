@@ -49,6 +49,7 @@ struct OtwArgs {
     int path_cap, live_cap;   // live_cap = 2N (otw_eran.py:14)
     int ref_f64, live_f64;
     int clamp_len;            // run mode: never read past live_stride frames
+    long long *debug;         // diagnostic builds only (-DRTS_OTW_STAMPS): [B][16] cycle sums
 };
 
 template <int W>
@@ -64,9 +65,12 @@ struct OtwLds {
     double refw[kF][W];   // feature-major ring of reference frames (index y & (W-1))
     double livew[kF][W];  // feature-major ring of live frames      (index x & (W-1))
     double row_last, col_last;
+    double rb_min, cb_min;        // np.argmin state of the two bands at the last decide()
+    double rfresh_min, cfresh_min;  // argmin of the strip just computed (chain waves -> decide)
     long long cells;
     int t, j, dir, prev, run_count, status, first, n_path, consumed, rows, cols;
     int pending_col, truncated, pend_dir, last_x, last_y;
+    int rb_idx, cb_idx, rfresh_idx, cfresh_idx, recomputes;
 };
 
 // Band position -> LDS slot.  Cell k lives at row (k mod L), column (k / L mod 64): the chain
@@ -116,11 +120,24 @@ __device__ __forceinline__ double cell_cost(const double (&lf)[kF], const double
     return euclid ? euclid12(lf, rf) : (1.0 - dot_strided12(lf, rf));
 }
 
-// lane i receives lane i-1's value; lane 0 receives `lane0`.
+// v_min_f64 without the canonicalising v_max pair hipcc adds around fmin().  Operands are never NaN
+// on this path (costs of finite chroma; the +inf sentinel is handled exactly by the instruction).
+__device__ __forceinline__ double vmin(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// lane i receives lane i-1's value; lane 0 receives `lane0`.  The s_nop covers the VALU-write ->
+// DPP-read hazard for a source produced by the preceding (asm or compiler) instruction.
 __device__ __forceinline__ double wave_shift_up(double v, double lane0) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), __double2loint(v), 0x138 /*wave_shr:1*/,
-                                               0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    int lo = __double2loint(lane0), hi = __double2hiint(lane0);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(lo), "+v"(hi)
+        : "v"(__double2loint(v)), "v"(__double2hiint(v)));
     return __hiloint2double(hi, lo);
 }
 
@@ -130,12 +147,37 @@ __device__ __forceinline__ double wave_bcast(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// Minimum over the 64 lanes, returned in every lane.  Six DPP steps (row_shr 1/2/4/8, then
+// row_bcast 15 and 31) leave the total in lane 63; lanes without a DPP source keep their own value.
+#define RTS_DPP_MIN_STEP(CTRL)                                                   \
+    do {                                                                         \
+        int tlo = __double2loint(x), thi = __double2hiint(x);                    \
+        asm volatile("s_nop 1\n\t"                                               \
+                     "v_mov_b32_dpp %0, %2 " CTRL "\n\t"                         \
+                     "v_mov_b32_dpp %1, %3 " CTRL                                \
+                     : "+v"(tlo), "+v"(thi)                                      \
+                     : "v"(__double2loint(x)), "v"(__double2hiint(x)));          \
+        x = vmin(x, __hiloint2double(thi, tlo));                                 \
+    } while (0)
+
+__device__ __forceinline__ double wave_min(double x) {
+    RTS_DPP_MIN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf");
+    RTS_DPP_MIN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
+    RTS_DPP_MIN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf");
+    RTS_DPP_MIN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf");
+    RTS_DPP_MIN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    RTS_DPP_MIN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    return wave_bcast(x, 63);
+}
+
 // Exact solution of acc_i = min(A_i, acc_{i-1} + D_i), i in [0, n), acc_{-1} = x_in, for the strip
 // whose cell i sits at band position k1 + i.  One wave; writes out[swz(k1+i)], returns acc_{n-1}
-// (x_in if n == 0) in every lane.
+// (x_in if n == 0) in every lane.  Also returns np.argmin (first minimum) of the new strip
+// restricted to band positions >= lo_arg: (fmin, fidx), fidx = 0x7fffffff if that range is empty.
 template <int W>
 __device__ __forceinline__ double strip_chain(const double *__restrict__ Dv, const double *__restrict__ Av,
-                                              double *__restrict__ out, int k1, int n, double x_in, int lane) {
+                                              double *__restrict__ out, int k1, int n, double x_in, int lane,
+                                              int lo_arg, double &fmin_out, int &fidx_out) {
     constexpr int L = W / 64;
     const double inf = INFINITY;
     double A[L], D[L], v[L];
@@ -152,7 +194,7 @@ __device__ __forceinline__ double strip_chain(const double *__restrict__ Dv, con
 #pragma unroll
     for (int m = 0; m < L; m++) {
         p = p + D[m];
-        v[m] = dmin(A[m], p);
+        v[m] = vmin(A[m], p);
         p = v[m];
     }
     // further rounds: carry-in = left neighbour's current last value.  Values only ever decrease
@@ -162,19 +204,37 @@ __device__ __forceinline__ double strip_chain(const double *__restrict__ Dv, con
     // (NaN != NaN) from spinning forever.
     for (int round = 0; round < 64; round++) {
         double q = wave_shift_up(v[L - 1], x_in);
-        const double before = v[L - 1];
+        // a carry that is already beaten at the lane's first cell can never win further right
+        // (monotonicity), so if that holds in every lane the strip is final
+        q = q + D[0];
+        if (!__any(q < v[0])) break;
+        v[0] = vmin(v[0], q);
 #pragma unroll
-        for (int m = 0; m < L; m++) {
+        for (int m = 1; m < L; m++) {
             q = q + D[m];
-            v[m] = dmin(v[m], q);
+            v[m] = vmin(v[m], q);
         }
-        if (!__any(v[L - 1] != before)) break;
     }
+    double lm = inf;
 #pragma unroll
     for (int m = 0; m < L; m++) {
         const int i = L * lane + m;
-        if (i < n) out[swz<W>(k1 + i)] = v[m];
+        if (i < n) {
+            out[swz<W>(k1 + i)] = v[m];
+            if (k1 + i >= lo_arg) lm = vmin(lm, v[m]);
+        }
     }
+    // first minimum: lowest lane holding the wave minimum, then its first matching cell
+    const double g = wave_min(lm);
+    int cand = 0x7fffffff;
+#pragma unroll
+    for (int m = L - 1; m >= 0; m--) {
+        const int i = L * lane + m;
+        if (i < n && k1 + i >= lo_arg && v[m] == g) cand = k1 + i;
+    }
+    const unsigned long long mask = __ballot(cand != 0x7fffffff);
+    fmin_out = g;
+    fidx_out = mask ? __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(mask)) : 0x7fffffff;
     if (n == 0) return x_in;
     const int li = n - 1;
     double mine = v[0];
@@ -183,36 +243,56 @@ __device__ __forceinline__ double strip_chain(const double *__restrict__ Dv, con
     return wave_bcast(mine, li / L);
 }
 
-// np.argmin over band[lo..hi] (first minimum).  One wave; results uniform.
+// np.argmin over band[lo..hi] (first minimum); (inf, 0x7fffffff) for an empty range.  One wave;
+// results uniform.  Only used when an incrementally maintained band minimum has left the window.
 template <int W>
 __device__ __forceinline__ void band_argmin(const double *__restrict__ band, int lo, int hi, int lane,
-                                            double &vmin, int &imin) {
+                                            double &vmin_out, int &imin) {
     constexpr int L = W / 64;
-    double best = INFINITY;
-    int bi = 0x7fffffff;
+    double v[L];
+    double lm = INFINITY;
 #pragma unroll
     for (int m = 0; m < L; m++) {
         const int k = lo + L * lane + m;
-        if (k <= hi) {
-            const double v = band[swz<W>(k)];
-            if (bi == 0x7fffffff || v < best) {
-                best = v;
-                bi = k;
-            }
-        }
+        v[m] = (k <= hi) ? band[swz<W>(k)] : (double)INFINITY;
+        if (k <= hi) lm = vmin(lm, v[m]);
     }
-    double g = best;
+    const double g = wave_min(lm);
+    int cand = 0x7fffffff;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) g = dmin(g, __shfl_xor(g, off));
-    const unsigned long long mask = __ballot(best == g && bi != 0x7fffffff);
-    const int src = mask ? (int)__builtin_ctzll(mask) : 0;
-    vmin = g;
-    imin = __builtin_amdgcn_readlane(bi, src);
+    for (int m = L - 1; m >= 0; m--) {
+        const int k = lo + L * lane + m;
+        if (k <= hi && v[m] == g) cand = k;
+    }
+    const unsigned long long mask = __ballot(cand != 0x7fffffff);
+    vmin_out = g;
+    imin = mask ? __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(mask)) : 0x7fffffff;
 }
+
+// In-kernel cycle stamps exist only in the diagnostic build (tools/otw_phase_profile.py); the
+// shipped library compiles them away.
+#ifdef RTS_OTW_STAMPS
+#define RTS_STAMP(slot)                                                   \
+    do {                                                                  \
+        const long long now_ = (long long)__builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               \
+        stamp_sum[slot] += now_ - stamp_last;                             \
+        stamp_last = now_;                                                \
+    } while (0)
+#else
+#define RTS_STAMP(slot) \
+    do {                \
+    } while (0)
+#endif
 
 template <int W, int NW>
 __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     constexpr int NT = 64 * NW;
+#ifdef RTS_OTW_STAMPS
+    long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_last = (long long)__builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     extern __shared__ __align__(16) unsigned char smem_raw[];
     OtwLds<W> &S = *reinterpret_cast<OtwLds<W> *>(smem_raw);
 
@@ -247,6 +327,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         S.cells = ((long long)(uint32_t)st[RTS_ST_CELLS_HI] << 32) | (uint32_t)st[RTS_ST_CELLS_LO];
         S.truncated = st[RTS_ST_PATH_TRUNCATED];
         S.pending_col = 0;
+        S.recomputes = st[RTS_ST_BAND_RECOMPUTES];
         S.pend_dir = st[14];
         S.last_x = -1;
         S.last_y = -1;
@@ -308,15 +389,65 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     };
 
     // ---- decide(): best_point + path + direction (otw_eran.py:153-211, livenote_v2.py:193-236).
-    // Called by every lane of wave 0 with the post-strip (t, j).
-    auto decide = [&](int t, int j) {
-        double rmin, cmin;
-        int ridx, cidx;
+    // Called by every lane of wave 0 with the post-strip (t, j).  The two band argmins are kept
+    // incrementally: a strip computed this step brings its own argmin from the chain wave; a band
+    // that merely slid by one cell keeps its minimum unless that cell left the window (then a full
+    // wave reduction over the band recomputes it); the one cell appended at the top index wins only
+    // if strictly smaller (np.argmin returns the first minimum).
+    auto decide = [&](int t, int j, bool row_fresh, bool col_fresh, bool row_corner, bool col_corner,
+                      bool full) {
         const int j1 = (j - c + 1 > 0) ? j - c + 1 : 0;
         const int t1 = (t - c + 1 > 0) ? t - c + 1 : 0;
-        band_argmin<W>(S.R, j1, j, lane, rmin, ridx);
-        band_argmin<W>(S.C, t1, t, lane, cmin, cidx);
+        double rmin, cmin;
+        int ridx, cidx;
+        if (full) {
+            band_argmin<W>(S.R, j1, j, lane, rmin, ridx);
+            band_argmin<W>(S.C, t1, t, lane, cmin, cidx);
+        } else {
+            // row band: positions [j1, j]; the top cell j is a corner appended by a column strip
+            if (row_fresh) {
+                rmin = S.rfresh_min;
+                ridx = S.rfresh_idx;
+            } else {
+                rmin = S.rb_min;
+                ridx = S.rb_idx;
+                if (ridx < j1) {  // uniform: the old minimum slid out of the window
+                    band_argmin<W>(S.R, j1, row_corner ? j - 1 : j, lane, rmin, ridx);
+                    if (lane == 0) S.recomputes += 1;
+                }
+            }
+            if (row_corner) {
+                const double rc = S.R[swz<W>(j)];
+                if (rc < rmin) {
+                    rmin = rc;
+                    ridx = j;
+                }
+            }
+            // column band: positions [t1, t]; the top cell t is appended by a row strip or is the corner
+            if (col_fresh) {
+                cmin = S.cfresh_min;
+                cidx = S.cfresh_idx;
+            } else {
+                cmin = S.cb_min;
+                cidx = S.cb_idx;
+                if (cidx < t1) {
+                    band_argmin<W>(S.C, t1, col_corner ? t - 1 : t, lane, cmin, cidx);
+                    if (lane == 0) S.recomputes += 1;
+                }
+            }
+            if (col_corner) {
+                const double cc = S.C[swz<W>(t)];
+                if (cc < cmin) {
+                    cmin = cc;
+                    cidx = t;
+                }
+            }
+        }
         if (lane == 0) {
+            S.rb_min = rmin;
+            S.rb_idx = ridx;
+            S.cb_min = cmin;
+            S.cb_idx = cidx;
             int x, y;
             if (rmin < cmin) {
                 x = t;
@@ -394,7 +525,15 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         }
         __syncthreads();
         if (a.mode == RTS_MODE_SET_LIVE) {
-            if (wave == 0) decide(0, 0);
+            if (wave == 0) decide(0, 0, false, false, false, false, true);
+            __syncthreads();
+        } else {
+            if (tid == 0) {  // both bands hold the single cell (0,0)
+                S.rb_min = S.R[swz<W>(0)];
+                S.cb_min = S.rb_min;
+                S.rb_idx = 0;
+                S.cb_idx = 0;
+            }
             __syncthreads();
         }
     } else {
@@ -412,10 +551,24 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         live_hi = t;
         ref_hi = j;
         __syncthreads();
+        if (wave == 0) {  // band minima are not persisted: rebuild them from the reloaded bands
+            double rmin, cmin;
+            int ridx, cidx;
+            band_argmin<W>(S.R, (j - c + 1 > 0) ? j - c + 1 : 0, j, lane, rmin, ridx);
+            band_argmin<W>(S.C, (t - c + 1 > 0) ? t - c + 1 : 0, t, lane, cmin, cidx);
+            if (lane == 0) {
+                S.rb_min = rmin;
+                S.rb_idx = ridx;
+                S.cb_min = cmin;
+                S.cb_idx = cidx;
+            }
+        }
+        __syncthreads();
     }
 
     // ---- step loop: one iteration = one row strip and/or one column strip + one decide()
     for (;;) {
+        RTS_STAMP(0);
         const int t0 = S.t, j0 = S.j, dir = S.dir, pending_col = S.pending_col;
         bool do_row, do_col;
         int t = t0;
@@ -447,6 +600,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, nr = j0 - k1r + 1;  // row strip: columns
         const int k1c = (t - c + 1 > 0) ? t - c + 1 : 0, nc = t - k1c + 1;     // column strip: rows
         const bool col_active = do_col && !stop;
+        RTS_STAMP(1);
 
         // -- cost phase
         if (do_row) {
@@ -484,28 +638,41 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 S.Ac[swz<W>(k)] = av;
             }
         }
+        RTS_STAMP(2);
         __syncthreads();
+        RTS_STAMP(3);
 
         // -- chain phase: row strip on wave 0, column strip on wave 1 when both exist
         const int col_wave = (NW > 1 && do_row) ? 1 : 0;
         if (do_row && wave == 0) {
             const double x_in = (k1r > 0) ? sentinel : inf;  // (t, k1r-1) was never evaluated
-            const double last = strip_chain<W>(S.Dr, S.Ar, S.R, k1r, nr, x_in, lane);
+            const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // row band's lower end at decide()
+            double fm;
+            int fi;
+            const double last = strip_chain<W>(S.Dr, S.Ar, S.R, k1r, nr, x_in, lane, lo_arg, fm, fi);
             if (lane == 0) {
                 if (k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
                 S.row_last = last;
+                S.rfresh_min = fm;
+                S.rfresh_idx = fi;
             }
         }
         if (col_active && wave == col_wave) {
             const double x_in = (k1c > 0) ? sentinel : inf;  // (k1c-1, jn) was never evaluated
             const int ncc = nc - (do_row ? 1 : 0);            // corner cell waits for the row strip
-            const double last = strip_chain<W>(S.Dc, S.Ac, S.C, k1c, ncc, x_in, lane);
+            double fm;
+            int fi;
+            const double last = strip_chain<W>(S.Dc, S.Ac, S.C, k1c, ncc, x_in, lane, k1c, fm, fi);
             if (lane == 0) {
                 if (k1c > 0) S.C[swz<W>(k1c - 1)] = sentinel;
                 S.col_last = last;
+                S.cfresh_min = fm;
+                S.cfresh_idx = fi;
             }
         }
+        RTS_STAMP(4);
         __syncthreads();
+        RTS_STAMP(5);
 
         // -- corner fix-up + decide (wave 0)
         if (wave == 0) {
@@ -537,9 +704,15 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (!stop) decide(t, jn);
+            RTS_STAMP(6);
+            // row band: fresh from this step's row strip, plus the corner a column strip appended;
+            // column band: fresh from this step's column strip (its corner cell was finished by the
+            // fix-up, outside the chain), or the old band plus the row strip's last cell
+            if (!stop) decide(t, jn, do_row, col_active, col_active, do_row, false);
+            RTS_STAMP(7);
         }
         __syncthreads();
+        RTS_STAMP(8);
         if (S.status != RTS_RUNNING) break;
     }
     __syncthreads();
@@ -558,6 +731,10 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             bb[(c + 1) + i] = (have && x >= 0 && x <= S.t) ? S.C[swz<W>(x)] : qnan;
         }
     }
+#ifdef RTS_OTW_STAMPS
+    if (tid == 0 && a.debug)
+        for (int i = 0; i < 12; i++) a.debug[(size_t)b * 16 + i] = stamp_sum[i];
+#endif
     if (tid == 0) {
         st[RTS_ST_T] = S.t;
         st[RTS_ST_J] = S.j;
@@ -575,7 +752,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         st[RTS_ST_CELLS_HI] = (int32_t)(uint32_t)((unsigned long long)S.cells >> 32);
         st[RTS_ST_PATH_TRUNCATED] = S.truncated;
         st[14] = S.pend_dir;
-        st[15] = S.dir;  // working direction, used when a run is resumed by rts_otw_insert
+        st[RTS_ST_BAND_RECOMPUTES] = S.recomputes;
     }
 }
 
@@ -591,7 +768,6 @@ __global__ void otw_reset_kernel(int32_t *state, int B, int variant) {
     st[RTS_ST_STATUS] = RTS_RUNNING;
     st[RTS_ST_FIRST_INSERT] = 1;
     st[14] = -2;
-    st[15] = RTS_DIR_BOTH;
 }
 
 // Append one frame per (active) stream to the handle-owned history and bump its length.
@@ -625,7 +801,7 @@ struct rts_otw {
     double *bands;      // [B][2][c+1]
     double *hist;       // [B][live_cap][F], allocated on first insert
     int32_t *hist_len;  // [B]
-    int resumed_dir_fixup;
+    long long *debug;   // diagnostic builds only
 };
 
 namespace rts {
@@ -680,6 +856,7 @@ static OtwArgs base_args(const rts_otw *h) {
     a.path_cap = h->path_cap;
     a.live_cap = h->live_cap;
     a.ref_f64 = h->ref_dtype == RTS_F64;
+    a.debug = h->debug;
     return a;
 }
 
@@ -820,10 +997,7 @@ int rts_otw_read_states(rts_otw *h, int32_t *states, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     RTS_HIP(hipMemcpyAsync(states, h->state, sizeof(int32_t) * RTS_STATE_LEN * (size_t)h->B, hipMemcpyDeviceToHost, s));
     RTS_HIP(hipStreamSynchronize(s));
-    for (int b = 0; b < h->B; b++) {  // slots 14/15 are kernel-private
-        states[b * RTS_STATE_LEN + 14] = 0;
-        states[b * RTS_STATE_LEN + 15] = 0;
-    }
+    for (int b = 0; b < h->B; b++) states[b * RTS_STATE_LEN + 14] = 0;  // slot 14 is kernel-private
     return RTS_OK;
 }
 
@@ -836,7 +1010,6 @@ int rts_otw_read_state(rts_otw *h, int b, int32_t *state, void *stream) {
                            hipMemcpyDeviceToHost, s));
     RTS_HIP(hipStreamSynchronize(s));
     state[14] = 0;
-    state[15] = 0;
     return RTS_OK;
 }
 
@@ -871,6 +1044,15 @@ int rts_otw_read_bands(rts_otw *h, int b, double *row_band, double *col_band, vo
     RTS_HIP(hipStreamSynchronize(s));
     return RTS_OK;
 }
+
+#ifdef RTS_OTW_STAMPS
+/* Diagnostic build only: caller-provided [B][16] int64 device buffer receiving per-phase cycle sums. */
+int rts_otw_set_debug(rts_otw *h, long long *debug_dev) {
+    if (!h) return rts::set_error(RTS_ERR_INVALID, "handle is NULL");
+    h->debug = debug_dev;
+    return RTS_OK;
+}
+#endif
 
 int rts_otw_device_views(rts_otw *h, int32_t **path_dev, int *path_cap, int32_t **state_dev) {
     using namespace rts;

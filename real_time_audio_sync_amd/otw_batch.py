@@ -112,7 +112,7 @@ class BatchedOTW:
                     status=int(s[nat.ST_STATUS]), first_insert=int(s[nat.ST_FIRST_INSERT]),
                     n_path=int(s[nat.ST_N_PATH]), consumed=int(s[nat.ST_CONSUMED]),
                     row_strips=int(s[nat.ST_ROW_STRIPS]), col_strips=int(s[nat.ST_COL_STRIPS]), cells=cells,
-                    path_truncated=int(s[nat.ST_PATH_TRUNCATED]))
+                    path_truncated=int(s[nat.ST_PATH_TRUNCATED]), band_recomputes=int(s[nat.ST_BAND_RECOMPUTES]))
 
     def path(self, b=0):
         n = ctypes.c_int(0)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Diagnostic (not shipped): build librtsync with -DRTS_OTW_STAMPS into tools/_diag/ and print
+the share of wave-0 cycles each phase of otw_advance_kernel takes on the bench workload."""
+import ctypes, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DIAG = os.path.join(ROOT, "tools", "_diag")
+
+
+def build():
+    os.makedirs(DIAG, exist_ok=True)
+    so = os.path.join(DIAG, "librtsync_diag.so")
+    src = [os.path.join(ROOT, "real_time_audio_sync_amd", "csrc", f) for f in ("common.cpp", "otw.hip")]
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off", "-fno-fast-math", "-DRTS_OTW_STAMPS", "-o", so]
+    for s in src:
+        cmd += ["-x", "hip", s]
+    subprocess.check_call(cmd)
+    return so
+
+
+def main():
+    so = os.path.join(DIAG, "librtsync_diag.so")
+    if "--build" in sys.argv or not os.path.exists(so):
+        build()
+        if "--build" in sys.argv:
+            return
+    import torch
+    from real_time_audio_sync_amd import synth
+    L = ctypes.CDLL(so)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int
+    L.rts_otw_create.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(vp)]
+    L.rts_otw_run.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    L.rts_otw_set_debug.argtypes = [vp, vp]
+    L.rts_otw_set_waves.argtypes = [vp, i32]
+    L.rts_otw_read_states.argtypes = [vp, vp, vp]
+    B, N, c = 64, 2200, 500
+    ref = synth.synth_ref(N, seed=1000)
+    lives = [synth.synth_live(ref, seed=1001 + b) for b in range(B)]
+    dev = torch.device("cuda:0")
+    ref_d = torch.from_numpy(np.ascontiguousarray(ref.T)).float().to(dev)
+    tmax = max(l.shape[1] for l in lives)
+    buf = torch.zeros((B, tmax, 12), dtype=torch.float32)
+    for b, l in enumerate(lives):
+        buf[b, :l.shape[1]] = torch.from_numpy(l.T.copy()).float()
+    live_d = buf.to(dev)
+    len_d = torch.tensor([l.shape[1] for l in lives], dtype=torch.int32, device=dev)
+    names = ["top(read state)", "ensure+plan", "cost phase", "barrier1", "chain", "barrier2", "fixup", "decide", "barrier3"]
+    for waves in (1, 2, 4, 8):
+        h = vp()
+        assert L.rts_otw_create(ref_d.data_ptr(), 0, 12, N, B, c, 3, 0, 0, ctypes.byref(h)) == 0
+        L.rts_otw_set_waves(h, waves)
+        dbg = torch.zeros((B, 16), dtype=torch.int64, device=dev)
+        L.rts_otw_set_debug(h, dbg.data_ptr())
+        for _ in range(2):
+            L.rts_otw_run(h, live_d.data_ptr(), 0, tmax, len_d.data_ptr(), 0, None)
+        torch.cuda.synchronize()
+        st = np.zeros((B, 16), dtype=np.int32)
+        L.rts_otw_read_states(h, st.ctypes.data, None)
+        d = dbg.cpu().numpy().astype(np.float64)
+        frames = st[:, 8].sum()
+        steps = d[:, :9].sum(axis=1)
+        tot = d[:, :9].sum()
+        print("waves=%d: wave-0 cycles (100 MHz ticks?) per frame: %.0f ; shares:" % (waves, tot / frames))
+        for i, nme in enumerate(names):
+            print("   %-18s %6.1f %%   (%.0f per frame)" % (nme, 100 * d[:, i].sum() / tot, d[:, i].sum() / frames))
+
+
+if __name__ == "__main__":
+    main()
