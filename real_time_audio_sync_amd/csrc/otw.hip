@@ -56,21 +56,18 @@ template <int W>
 struct OtwLds {
     static constexpr int L = W / 64;     // cells per lane in the chain phase
     static constexpr int SWZ = L * 65;   // swizzled band length (one pad slot per row of 64)
-    double R[SWZ];   // acc[t][.]  row band
-    double C[SWZ];   // acc[.][j]  column band
-    double Dr[SWZ];  // row strip: cell costs
-    double Ar[SWZ];  // row strip: min over the two out-of-strip predecessors
-    double Dc[SWZ];
+    double R[SWZ];      // acc[t][.]  row band
+    double C[SWZ];      // acc[.][j]  column band
+    double Dr[2][SWZ];  // row strip cell costs: [buf] = this step's, [buf^1] = being pre-computed for the next
+    double Dc[2][SWZ];
+    double Ar[SWZ];     // row strip: min over the two out-of-strip predecessors
     double Ac[SWZ];
     double refw[kF][W];   // feature-major ring of reference frames (index y & (W-1))
     double livew[kF][W];  // feature-major ring of live frames      (index x & (W-1))
-    double row_last, col_last;
-    double rb_min, cb_min;        // np.argmin state of the two bands at the last decide()
-    double rfresh_min, cfresh_min;  // argmin of the strip just computed (chain waves -> decide)
-    long long cells;
-    int t, j, dir, prev, run_count, status, first, n_path, consumed, rows, cols;
-    int pending_col, truncated, pend_dir, last_x, last_y;
-    int rb_idx, cb_idx, rfresh_idx, cfresh_idx, recomputes;
+    double col_last, cfresh_min;  // column chain wave -> wave 0
+    int cfresh_idx;
+    int plan_t, plan_j0, plan_flags;  // wave 0 -> everyone: the next step
+    int t, j;                         // final position, published at exit for the epilogue
 };
 
 // Band position -> LDS slot.  Cell k lives at row (k mod L), column (k / L mod 64): the chain
@@ -288,6 +285,11 @@ __device__ __forceinline__ void band_argmin(const double *__restrict__ band, int
 template <int W, int NW>
 __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     constexpr int NT = 64 * NW;
+    // Waves >= HW0 pre-compute the next step's cell costs while waves 0/1 run the chains.  With fewer
+    // than 4 waves there are no spare ones and every wave does its share after its chain.
+    constexpr int HW0 = (NW >= 4) ? 2 : 0;
+    constexpr int NHELP = 64 * (NW - HW0);
+    constexpr int kPlanRow = 1, kPlanCol = 2, kPlanStop = 4, kPlanExit = 8;
 #ifdef RTS_OTW_STAMPS
     long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long stamp_last = (long long)__builtin_amdgcn_s_memtime();
@@ -312,50 +314,40 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     // LiveNote's set_live applies the run-count update at the bottom of its loop (livenote_v2.py:149-155)
     const bool deferred_update = (a.mode == RTS_MODE_SET_LIVE) && (a.variant != RTS_VARIANT_OTW);
 
-    if (tid == 0) {
-        S.t = st[RTS_ST_T];
-        S.j = st[RTS_ST_J];
-        S.dir = st[RTS_ST_DIRECTION];
-        S.prev = st[RTS_ST_PREVIOUS];
-        S.run_count = st[RTS_ST_RUN_COUNT];
-        S.status = st[RTS_ST_STATUS];
-        S.first = st[RTS_ST_FIRST_INSERT];
-        S.n_path = st[RTS_ST_N_PATH];
-        S.consumed = st[RTS_ST_CONSUMED];
-        S.rows = st[RTS_ST_ROW_STRIPS];
-        S.cols = st[RTS_ST_COL_STRIPS];
-        S.cells = ((long long)(uint32_t)st[RTS_ST_CELLS_HI] << 32) | (uint32_t)st[RTS_ST_CELLS_LO];
-        S.truncated = st[RTS_ST_PATH_TRUNCATED];
-        S.pending_col = 0;
-        S.recomputes = st[RTS_ST_BAND_RECOMPUTES];
-        S.pend_dir = st[14];
-        S.last_x = -1;
-        S.last_y = -1;
-        if (S.n_path > 0 && S.n_path <= a.path_cap) {
-            const int32_t *pp = a.path + ((size_t)b * a.path_cap + (S.n_path - 1)) * 2;
-            S.last_x = pp[0];
-            S.last_y = pp[1];
-        }
+    // ---- control state.  Every thread loads it (uniform), but only wave 0 keeps it current: it lives
+    // in wave 0's registers for the whole launch and reaches the other waves as a 3-word plan in LDS.
+    int t = st[RTS_ST_T], j = st[RTS_ST_J], dir = st[RTS_ST_DIRECTION], prev = st[RTS_ST_PREVIOUS];
+    int run_count = st[RTS_ST_RUN_COUNT], status = st[RTS_ST_STATUS], first = st[RTS_ST_FIRST_INSERT];
+    int n_path = st[RTS_ST_N_PATH], consumed = st[RTS_ST_CONSUMED], rows = st[RTS_ST_ROW_STRIPS];
+    int cols = st[RTS_ST_COL_STRIPS], truncated = st[RTS_ST_PATH_TRUNCATED], pend_dir = st[14];
+    int recomputes = st[RTS_ST_BAND_RECOMPUTES];
+    long long cells = ((long long)(uint32_t)st[RTS_ST_CELLS_HI] << 32) | (uint32_t)st[RTS_ST_CELLS_LO];
+    int pending_col = 0, last_x = -1, last_y = -1;
+    if (n_path > 0 && n_path <= a.path_cap) {
+        const int32_t *pp = a.path + ((size_t)b * a.path_cap + (n_path - 1)) * 2;
+        last_x = pp[0];
+        last_y = pp[1];
     }
-    __syncthreads();
-    if (S.status == RTS_STOP_REF_END) return;  // sticky; the reference's callers stop inserting
-    if (S.status == RTS_LIVE_OVERFLOW) {       // otw_eran.py:50-55: t keeps counting inserts
-        if (tid == 0 && live_len > S.consumed) {
+    double rb_min = inf, cb_min = inf;
+    int rb_idx = 0, cb_idx = 0;
+
+    if (status == RTS_STOP_REF_END) return;  // sticky; the reference's callers stop inserting
+    if (status == RTS_LIVE_OVERFLOW) {       // otw_eran.py:50-55: t keeps counting inserts
+        if (tid == 0 && live_len > consumed) {
             st[RTS_ST_T] = live_len - 1;
             st[RTS_ST_CONSUMED] = live_len;
         }
         return;
     }
-    if (live_len <= S.consumed) return;  // nothing new
+    if (live_len <= consumed) return;  // nothing new
 
-    // ---- ring refills (uniform control flow: live_hi / ref_hi are identical in every thread)
-    int live_hi = -1, ref_hi = -1;
+    // ---- feature rings
     auto load_feat = [&](const void *base, int is_f64, long long idx) -> double {
         return is_f64 ? reinterpret_cast<const double *>(base)[idx]
                       : (double)reinterpret_cast<const float *>(base)[idx];
     };
     const long long live_base = (long long)b * a.live_stride * kF;
-    auto fill_live = [&](int lo, int hi) {  // frames lo..hi -> ring
+    auto fill_live = [&](int lo, int hi) {  // synchronous, all threads (prologue only)
         for (int idx = tid; idx < (hi - lo + 1) * kF; idx += NT) {
             const int fr = lo + idx / kF, f = idx % kF;
             S.livew[f][fr & (W - 1)] = load_feat(a.live, a.live_f64, live_base + (long long)fr * kF + f);
@@ -367,146 +359,240 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             S.refw[f][fr & (W - 1)] = load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
         }
     };
-    auto ensure_live = [&](int need) {
-        if (need > live_hi) {
-            int hi = live_hi + kFetch;
-            if (hi < need) hi = need;
-            if (hi > live_len - 1) hi = live_len - 1;
-            fill_live(live_hi + 1, hi);
-            live_hi = hi;
-            __syncthreads();
-        }
+    // Asynchronous refills (wave 0): the next kFetch frames sit in two registers per lane, loaded a
+    // refill period (~8 steps) before they are written into the ring.
+    int live_hi = -1, ref_hi = -1;
+    double pfl0 = 0.0, pfl1 = 0.0, pfr0 = 0.0, pfr1 = 0.0;
+    auto prefetch_live = [&]() {  // frames live_hi+1 .. live_hi+kFetch
+        const int i0 = lane, i1 = lane + 64;
+        const int f0 = live_hi + 1 + i0 / kF, f1 = live_hi + 1 + i1 / kF;
+        if (f0 < live_len) pfl0 = load_feat(a.live, a.live_f64, live_base + (long long)f0 * kF + i0 % kF);
+        if (i1 < kFetch * kF && f1 < live_len)
+            pfl1 = load_feat(a.live, a.live_f64, live_base + (long long)f1 * kF + i1 % kF);
     };
-    auto ensure_ref = [&](int need) {
-        if (need > ref_hi) {
-            int hi = ref_hi + kFetch;
-            if (hi < need) hi = need;
-            if (hi > N - 1) hi = N - 1;
-            fill_ref(ref_hi + 1, hi);
-            ref_hi = hi;
-            __syncthreads();
+    auto prefetch_ref = [&]() {
+        const int i0 = lane, i1 = lane + 64;
+        const int f0 = ref_hi + 1 + i0 / kF, f1 = ref_hi + 1 + i1 / kF;
+        if (f0 < N) pfr0 = load_feat(a.ref, a.ref_f64, (long long)f0 * kF + i0 % kF);
+        if (i1 < kFetch * kF && f1 < N) pfr1 = load_feat(a.ref, a.ref_f64, (long long)f1 * kF + i1 % kF);
+    };
+    auto commit_live = [&]() {  // registers -> ring, then start fetching the following block
+        const int i0 = lane, i1 = lane + 64;
+        const int f0 = live_hi + 1 + i0 / kF, f1 = live_hi + 1 + i1 / kF;
+        if (f0 < live_len) S.livew[i0 % kF][f0 & (W - 1)] = pfl0;
+        if (i1 < kFetch * kF && f1 < live_len) S.livew[i1 % kF][f1 & (W - 1)] = pfl1;
+        live_hi = (live_hi + kFetch < live_len - 1) ? live_hi + kFetch : live_len - 1;
+        prefetch_live();
+    };
+    auto commit_ref = [&]() {
+        const int i0 = lane, i1 = lane + 64;
+        const int f0 = ref_hi + 1 + i0 / kF, f1 = ref_hi + 1 + i1 / kF;
+        if (f0 < N) S.refw[i0 % kF][f0 & (W - 1)] = pfr0;
+        if (i1 < kFetch * kF && f1 < N) S.refw[i1 % kF][f1 & (W - 1)] = pfr1;
+        ref_hi = (ref_hi + kFetch < N - 1) ? ref_hi + kFetch : N - 1;
+        prefetch_ref();
+    };
+
+    // ---- speculative costs for the step after the one that leaves the state at (t_now, j_now):
+    // row t_now+1 over columns [j_now-c+1, j_now] and column j_now+1 over rows [t_now-c+1, t_now+1]
+    // cover every possible next step (Row, Both or Column).  hidx/hn: index and count of the
+    // threads sharing the work.
+    auto precompute = [&](int t_now, int j_now, double *Drn, double *Dcn, int hidx, int hn) {
+        const int tn = t_now + 1, jn1 = j_now + 1;
+        const bool row_ok = (tn < live_len) && (tn < a.live_cap);
+        const bool col_ok = jn1 < N;
+        const int k1 = (j_now - c + 1 > 0) ? j_now - c + 1 : 0;
+        const int nrow = row_ok ? j_now - k1 + 1 : 0;
+        const int r1 = (t_now - c + 1 > 0) ? t_now - c + 1 : 0;
+        const int rtop = row_ok ? tn : t_now;
+        const int ncol = col_ok ? rtop - r1 + 1 : 0;
+        if (nrow > 0) {
+            double lf[kF];
+#pragma unroll
+            for (int f = 0; f < kF; f++) lf[f] = S.livew[f][tn & (W - 1)];
+            for (int i = hidx; i < nrow; i += hn) {
+                const int k = k1 + i;
+                double rf[kF];
+#pragma unroll
+                for (int f = 0; f < kF; f++) rf[f] = S.refw[f][k & (W - 1)];
+                Drn[swz<W>(k)] = cell_cost(lf, rf, euclid);
+            }
+        }
+        if (ncol > 0) {
+            double rf[kF];
+#pragma unroll
+            for (int f = 0; f < kF; f++) rf[f] = S.refw[f][jn1 & (W - 1)];
+            for (int i = hidx; i < ncol; i += hn) {
+                const int r = r1 + i;
+                double lf[kF];
+#pragma unroll
+                for (int f = 0; f < kF; f++) lf[f] = S.livew[f][r & (W - 1)];
+                Dcn[swz<W>(r)] = cell_cost(lf, rf, euclid);
+            }
         }
     };
 
     // ---- decide(): best_point + path + direction (otw_eran.py:153-211, livenote_v2.py:193-236).
-    // Called by every lane of wave 0 with the post-strip (t, j).  The two band argmins are kept
-    // incrementally: a strip computed this step brings its own argmin from the chain wave; a band
-    // that merely slid by one cell keeps its minimum unless that cell left the window (then a full
-    // wave reduction over the band recomputes it); the one cell appended at the top index wins only
-    // if strictly smaller (np.argmin returns the first minimum).
-    auto decide = [&](int t, int j, bool row_fresh, bool col_fresh, bool row_corner, bool col_corner,
-                      bool full) {
-        const int j1 = (j - c + 1 > 0) ? j - c + 1 : 0;
-        const int t1 = (t - c + 1 > 0) ? t - c + 1 : 0;
+    // Wave 0, all lanes, register state.  The two band argmins are kept incrementally: a strip
+    // computed this step brings its own argmin from its chain; a band that merely slid by one cell
+    // keeps its minimum unless that cell left the window (then a full wave reduction recomputes
+    // it); the one cell appended at the top index wins only if strictly smaller (np.argmin returns
+    // the first minimum).
+    auto decide = [&](int tt, int jj, bool row_fresh, double rf_min, int rf_idx, bool col_fresh, double cf_min,
+                      int cf_idx, bool row_corner, double rc, bool col_corner, double cc, bool full) {
+        const int j1 = (jj - c + 1 > 0) ? jj - c + 1 : 0;
+        const int t1 = (tt - c + 1 > 0) ? tt - c + 1 : 0;
         double rmin, cmin;
         int ridx, cidx;
         if (full) {
-            band_argmin<W>(S.R, j1, j, lane, rmin, ridx);
-            band_argmin<W>(S.C, t1, t, lane, cmin, cidx);
+            band_argmin<W>(S.R, j1, jj, lane, rmin, ridx);
+            band_argmin<W>(S.C, t1, tt, lane, cmin, cidx);
         } else {
-            // row band: positions [j1, j]; the top cell j is a corner appended by a column strip
             if (row_fresh) {
-                rmin = S.rfresh_min;
-                ridx = S.rfresh_idx;
+                rmin = rf_min;
+                ridx = rf_idx;
             } else {
-                rmin = S.rb_min;
-                ridx = S.rb_idx;
-                if (ridx < j1) {  // uniform: the old minimum slid out of the window
-                    band_argmin<W>(S.R, j1, row_corner ? j - 1 : j, lane, rmin, ridx);
-                    if (lane == 0) S.recomputes += 1;
+                rmin = rb_min;
+                ridx = rb_idx;
+                if (ridx < j1) {  // the old minimum slid out of the window
+                    band_argmin<W>(S.R, j1, row_corner ? jj - 1 : jj, lane, rmin, ridx);
+                    recomputes += 1;
                 }
             }
-            if (row_corner) {
-                const double rc = S.R[swz<W>(j)];
-                if (rc < rmin) {
-                    rmin = rc;
-                    ridx = j;
-                }
+            if (row_corner && rc < rmin) {
+                rmin = rc;
+                ridx = jj;
             }
-            // column band: positions [t1, t]; the top cell t is appended by a row strip or is the corner
             if (col_fresh) {
-                cmin = S.cfresh_min;
-                cidx = S.cfresh_idx;
+                cmin = cf_min;
+                cidx = cf_idx;
             } else {
-                cmin = S.cb_min;
-                cidx = S.cb_idx;
+                cmin = cb_min;
+                cidx = cb_idx;
                 if (cidx < t1) {
-                    band_argmin<W>(S.C, t1, col_corner ? t - 1 : t, lane, cmin, cidx);
-                    if (lane == 0) S.recomputes += 1;
+                    band_argmin<W>(S.C, t1, col_corner ? tt - 1 : tt, lane, cmin, cidx);
+                    recomputes += 1;
                 }
             }
-            if (col_corner) {
-                const double cc = S.C[swz<W>(t)];
-                if (cc < cmin) {
-                    cmin = cc;
-                    cidx = t;
-                }
+            if (col_corner && cc < cmin) {
+                cmin = cc;
+                cidx = tt;
             }
         }
-        if (lane == 0) {
-            S.rb_min = rmin;
-            S.rb_idx = ridx;
-            S.cb_min = cmin;
-            S.cb_idx = cidx;
-            int x, y;
-            if (rmin < cmin) {
-                x = t;
-                y = ridx;
-            } else {
-                x = cidx;
-                y = j;
-            }
-            bool append = true;
-            if (a.variant == RTS_VARIANT_LIVENOTE_V2)  // livenote_v2.py:198
-                append = (S.n_path == 0) || (x > S.last_x && y >= S.last_y);
-            if (append) {
-                if (S.n_path < a.path_cap) {
-                    int2 *pp = reinterpret_cast<int2 *>(a.path) + ((size_t)b * a.path_cap + S.n_path);
+        rb_min = rmin;
+        rb_idx = ridx;
+        cb_min = cmin;
+        cb_idx = cidx;
+        int x, y;
+        if (rmin < cmin) {
+            x = tt;
+            y = ridx;
+        } else {
+            x = cidx;
+            y = jj;
+        }
+        bool append = true;
+        if (a.variant == RTS_VARIANT_LIVENOTE_V2)  // livenote_v2.py:198
+            append = (n_path == 0) || (x > last_x && y >= last_y);
+        if (append) {
+            if (n_path < a.path_cap) {
+                if (lane == 0) {
+                    int2 *pp = reinterpret_cast<int2 *>(a.path) + ((size_t)b * a.path_cap + n_path);
                     *pp = make_int2(x, y);
-                } else {
-                    S.truncated = 1;
                 }
-                S.n_path += 1;
-                S.last_x = x;
-                S.last_y = y;
-            }
-            int nd;
-            if (t < c)
-                nd = RTS_DIR_BOTH;
-            else if (S.run_count >= a.max_run_count)
-                nd = (S.prev == RTS_DIR_ROW) ? RTS_DIR_COLUMN : RTS_DIR_ROW;
-            else if (x < t)
-                nd = RTS_DIR_COLUMN;
-            else if (y < j)
-                nd = RTS_DIR_ROW;
-            else
-                nd = RTS_DIR_BOTH;
-            if (deferred_update) {
-                S.pend_dir = nd;
             } else {
-                S.run_count = (nd == S.prev) ? S.run_count + 1 : 1;
-                if (nd != RTS_DIR_BOTH) S.prev = nd;
+                truncated = 1;
             }
-            S.dir = nd;
-            S.pending_col = (nd == RTS_DIR_COLUMN);
-            S.t = t;
-            S.j = j;
+            n_path += 1;
+            last_x = x;
+            last_y = y;
         }
+        int nd;
+        if (tt < c)
+            nd = RTS_DIR_BOTH;
+        else if (run_count >= a.max_run_count)
+            nd = (prev == RTS_DIR_ROW) ? RTS_DIR_COLUMN : RTS_DIR_ROW;
+        else if (x < tt)
+            nd = RTS_DIR_COLUMN;
+        else if (y < jj)
+            nd = RTS_DIR_ROW;
+        else
+            nd = RTS_DIR_BOTH;
+        if (deferred_update) {
+            pend_dir = nd;
+        } else {
+            run_count = (nd == prev) ? run_count + 1 : 1;
+            if (nd != RTS_DIR_BOTH) prev = nd;
+        }
+        dir = nd;
+        pending_col = (nd == RTS_DIR_COLUMN);
+        t = tt;
+        j = jj;
     };
-    auto apply_pending = [&]() {  // lane 0 of wave 0 only
-        if (deferred_update && S.pend_dir != -2) {
-            const int nd = S.pend_dir;
-            S.run_count = (nd == S.prev) ? S.run_count + 1 : 1;
-            if (nd != RTS_DIR_BOTH) S.prev = nd;
-            S.pend_dir = -2;
+
+    // ---- plan for the next step from the current register state (wave 0); lane 0 publishes it
+    auto make_plan = [&]() {
+        int flags = 0, pt = t;
+        if (status != RTS_RUNNING) {
+            flags = kPlanExit;
+        } else if (pending_col) {
+            flags = kPlanCol;
+        } else if (t + 1 >= live_len) {  // live sequence exhausted
+            if (a.mode == RTS_MODE_SET_LIVE) t = t + 1;  // otw_eran.py:111-115
+            flags = kPlanExit;
+        } else if (t + 1 >= a.live_cap) {  // otw_eran.py:53-55
+            status = RTS_LIVE_OVERFLOW;
+            t = live_len - 1;
+            consumed = live_len;
+            flags = kPlanExit;
+        } else {
+            pt = t + 1;
+            flags = kPlanRow | ((dir != RTS_DIR_ROW) ? kPlanCol : 0);
+        }
+        if ((flags & kPlanCol) && j + 1 >= N) flags |= kPlanStop;  // otw_eran.py:67-71
+        if (lane == 0) {
+            S.plan_t = pt;
+            S.plan_j0 = j;
+            S.plan_flags = flags;
+            if (flags & kPlanExit) {
+                S.t = t;
+                S.j = j;
+            }
+        }
+        // keep the rings one frame ahead of what this step's cost pre-computation will read
+        if (!(flags & kPlanExit)) {
+            const int jn_p = j + ((flags & kPlanCol) ? 1 : 0);
+            const int need_l = (pt + 1 < live_len - 1) ? pt + 1 : live_len - 1;
+            const int need_r = (jn_p + 1 < N - 1) ? jn_p + 1 : N - 1;
+            if (need_l > live_hi) commit_live();
+            if (need_r > ref_hi) commit_ref();
         }
     };
 
     // ---- prologue: first frame, or reload of the persisted bands / windows
-    if (S.first) {
-        ensure_live(0);
-        ensure_ref(0);
-        if (tid == 0) {
+    {
+        const int lo_l = (t - c + 1 > 0) ? t - c + 1 : 0;
+        const int lo_r = (j - c + 1 > 0) ? j - c + 1 : 0;
+        live_hi = (t + 2 < live_len - 1) ? t + 2 : live_len - 1;
+        ref_hi = (j + 2 < N - 1) ? j + 2 : N - 1;
+        fill_live(lo_l, live_hi);
+        fill_ref(lo_r, ref_hi);
+        if (!first) {
+            const double *bb = a.bands + (size_t)b * 2 * (c + 1);
+            for (int i = tid; i <= c; i += NT) {
+                const int y = j - c + i, x = t - c + i;
+                if (y >= 0) S.R[swz<W>(y)] = bb[i];
+                if (x >= 0) S.C[swz<W>(x)] = bb[(c + 1) + i];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            prefetch_live();
+            prefetch_ref();
+        }
+    }
+    if (first) {
+        if (wave == 0) {
             double lf[kF], rf[kF];
 #pragma unroll
             for (int f = 0; f < kF; f++) {
@@ -514,155 +600,96 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 rf[f] = S.refw[f][0];
             }
             const double d = cell_cost(lf, rf, euclid);
-            S.R[swz<W>(0)] = d;
-            S.C[swz<W>(0)] = d;
-            S.first = 0;
-            S.consumed = 1;
-            S.cells += 1;
-            S.t = 0;
-            S.j = 0;
-            S.pend_dir = -2;
-        }
-        __syncthreads();
-        if (a.mode == RTS_MODE_SET_LIVE) {
-            if (wave == 0) decide(0, 0, false, false, false, false, true);
-            __syncthreads();
-        } else {
-            if (tid == 0) {  // both bands hold the single cell (0,0)
-                S.rb_min = S.R[swz<W>(0)];
-                S.cb_min = S.rb_min;
-                S.rb_idx = 0;
-                S.cb_idx = 0;
-            }
-            __syncthreads();
-        }
-    } else {
-        const int t = S.t, j = S.j;
-        const double *bb = a.bands + (size_t)b * 2 * (c + 1);
-        for (int i = tid; i <= c; i += NT) {
-            const int y = j - c + i, x = t - c + i;
-            if (y >= 0) S.R[swz<W>(y)] = bb[i];
-            if (x >= 0) S.C[swz<W>(x)] = bb[(c + 1) + i];
-        }
-        const int lo_l = (t - c + 1 > 0) ? t - c + 1 : 0;
-        const int lo_r = (j - c + 1 > 0) ? j - c + 1 : 0;
-        fill_live(lo_l, t);
-        fill_ref(lo_r, j);
-        live_hi = t;
-        ref_hi = j;
-        __syncthreads();
-        if (wave == 0) {  // band minima are not persisted: rebuild them from the reloaded bands
-            double rmin, cmin;
-            int ridx, cidx;
-            band_argmin<W>(S.R, (j - c + 1 > 0) ? j - c + 1 : 0, j, lane, rmin, ridx);
-            band_argmin<W>(S.C, (t - c + 1 > 0) ? t - c + 1 : 0, t, lane, cmin, cidx);
             if (lane == 0) {
-                S.rb_min = rmin;
-                S.rb_idx = ridx;
-                S.cb_min = cmin;
-                S.cb_idx = cidx;
+                S.R[swz<W>(0)] = d;
+                S.C[swz<W>(0)] = d;
             }
+            first = 0;
+            consumed = 1;
+            cells += 1;
+            t = 0;
+            j = 0;
+            pend_dir = -2;
+            rb_min = d;
+            cb_min = d;
+            rb_idx = 0;
+            cb_idx = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (a.mode == RTS_MODE_SET_LIVE) decide(0, 0, false, 0.0, 0, false, 0.0, 0, false, 0.0, false, 0.0, true);
         }
-        __syncthreads();
+    } else if (wave == 0) {  // band minima are not persisted: rebuild them from the reloaded bands
+        band_argmin<W>(S.R, (j - c + 1 > 0) ? j - c + 1 : 0, j, lane, rb_min, rb_idx);
+        band_argmin<W>(S.C, (t - c + 1 > 0) ? t - c + 1 : 0, t, lane, cb_min, cb_idx);
     }
+    if (wave == 0) {
+        if (lane == 0) {
+            S.t = t;
+            S.j = j;
+        }
+    }
+    __syncthreads();
+    // prime the cost buffers for the first step (all threads), then publish its plan
+    int buf = 0;
+    precompute(S.t, S.j, S.Dr[0], S.Dc[0], tid, NT);
+    if (wave == 0) make_plan();
+    __syncthreads();
 
     // ---- step loop: one iteration = one row strip and/or one column strip + one decide()
     for (;;) {
         RTS_STAMP(0);
-        const int t0 = S.t, j0 = S.j, dir = S.dir, pending_col = S.pending_col;
-        bool do_row, do_col;
-        int t = t0;
-        if (pending_col) {
-            do_row = false;
-            do_col = true;
-        } else {
-            if (t0 + 1 >= live_len) {  // live sequence exhausted
-                if (tid == 0 && a.mode == RTS_MODE_SET_LIVE) S.t = t0 + 1;  // otw_eran.py:111-115
-                break;
-            }
-            t = t0 + 1;
-            if (t >= a.live_cap) {  // otw_eran.py:53-55
-                if (tid == 0) {
-                    S.status = RTS_LIVE_OVERFLOW;
-                    S.t = live_len - 1;
-                    S.consumed = live_len;
-                }
-                break;
-            }
-            do_row = true;
-            do_col = (dir != RTS_DIR_ROW);
-        }
+        const int pt = S.plan_t, j0 = S.plan_j0, pflags = S.plan_flags;
+        if (pflags & kPlanExit) break;
+        const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
+        const bool stop = (pflags & kPlanStop) != 0;
         const int jn = j0 + (do_col ? 1 : 0);
-        const bool stop = do_col && (jn >= N);  // otw_eran.py:67-71
-        if (do_row) ensure_live(t);
-        ensure_ref(stop ? j0 : jn);
-
         const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, nr = j0 - k1r + 1;  // row strip: columns
-        const int k1c = (t - c + 1 > 0) ? t - c + 1 : 0, nc = t - k1c + 1;     // column strip: rows
+        const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1;  // column strip: rows
         const bool col_active = do_col && !stop;
-        RTS_STAMP(1);
+        double *Dr = S.Dr[buf], *Dc = S.Dc[buf];
 
-        // -- cost phase
+        // -- predecessor phase: a = min over the two out-of-strip predecessors, costs are ready
         if (do_row) {
-            double lf[kF];
-#pragma unroll
-            for (int f = 0; f < kF; f++) lf[f] = S.livew[f][t & (W - 1)];
             for (int i = tid; i < nr; i += NT) {
                 const int k = k1r + i;
-                double rf[kF];
-#pragma unroll
-                for (int f = 0; f < kF; f++) rf[f] = S.refw[f][k & (W - 1)];
-                const double d = cell_cost(lf, rf, euclid);
+                const double d = Dr[swz<W>(k)];
                 double av = S.R[swz<W>(k)] + d;  // (t-1, k): always present
-                if (k > 0) av = dmin(av, S.R[swz<W>(k - 1)] + 2 * d);
-                S.Dr[swz<W>(k)] = d;
+                if (k > 0) av = vmin(av, S.R[swz<W>(k - 1)] + 2 * d);
                 S.Ar[swz<W>(k)] = av;
             }
         }
         if (col_active) {
-            double rf[kF];
-#pragma unroll
-            for (int f = 0; f < kF; f++) rf[f] = S.refw[f][jn & (W - 1)];
             for (int i = tid; i < nc; i += NT) {
                 const int k = k1c + i;
-                double lf[kF];
-#pragma unroll
-                for (int f = 0; f < kF; f++) lf[f] = S.livew[f][k & (W - 1)];
-                const double d = cell_cost(lf, rf, euclid);
+                const double d = Dc[swz<W>(k)];
                 // (k, jn-1) is C[k]; for the corner cell of a Both step it is this step's row
                 // result, so only the diagonal term is formed here and the rest in the fix-up.
-                const bool corner = do_row && (k == t);
+                const bool corner = do_row && (k == pt);
                 double av = corner ? inf : S.C[swz<W>(k)] + d;
-                if (k > 0) av = dmin(av, S.C[swz<W>(k - 1)] + 2 * d);
-                S.Dc[swz<W>(k)] = d;
+                if (k > 0) av = vmin(av, S.C[swz<W>(k - 1)] + 2 * d);
                 S.Ac[swz<W>(k)] = av;
             }
         }
-        RTS_STAMP(2);
+        RTS_STAMP(1);
         __syncthreads();
-        RTS_STAMP(3);
+        RTS_STAMP(2);
 
-        // -- chain phase: row strip on wave 0, column strip on wave 1 when both exist
+        // -- chain phase: row strip on wave 0, column strip on wave 1; spare waves pre-compute the
+        //    next step's costs meanwhile
         const int col_wave = (NW > 1 && do_row) ? 1 : 0;
+        double row_last = 0.0, rf_min = inf;
+        int rf_idx = 0x7fffffff;
         if (do_row && wave == 0) {
             const double x_in = (k1r > 0) ? sentinel : inf;  // (t, k1r-1) was never evaluated
             const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // row band's lower end at decide()
-            double fm;
-            int fi;
-            const double last = strip_chain<W>(S.Dr, S.Ar, S.R, k1r, nr, x_in, lane, lo_arg, fm, fi);
-            if (lane == 0) {
-                if (k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
-                S.row_last = last;
-                S.rfresh_min = fm;
-                S.rfresh_idx = fi;
-            }
+            row_last = strip_chain<W>(Dr, S.Ar, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx);
+            if (lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
         }
         if (col_active && wave == col_wave) {
             const double x_in = (k1c > 0) ? sentinel : inf;  // (k1c-1, jn) was never evaluated
             const int ncc = nc - (do_row ? 1 : 0);            // corner cell waits for the row strip
             double fm;
             int fi;
-            const double last = strip_chain<W>(S.Dc, S.Ac, S.C, k1c, ncc, x_in, lane, k1c, fm, fi);
+            const double last = strip_chain<W>(Dc, S.Ac, S.C, k1c, ncc, x_in, lane, k1c, fm, fi);
             if (lane == 0) {
                 if (k1c > 0) S.C[swz<W>(k1c - 1)] = sentinel;
                 S.col_last = last;
@@ -670,65 +697,75 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 S.cfresh_idx = fi;
             }
         }
+        RTS_STAMP(3);
+        if (!stop && wave >= HW0) precompute(pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
         RTS_STAMP(4);
         __syncthreads();
         RTS_STAMP(5);
 
-        // -- corner fix-up + decide (wave 0)
+        // -- corner fix-up, decide, next plan (wave 0, register state)
         if (wave == 0) {
-            if (lane == 0) {
-                if (!stop) apply_pending();  // livenote_v2.py:139-142 breaks before the update
-                if (do_row) {
-                    S.rows += 1;
-                    S.cells += nr;
-                    S.consumed = t + 1;
-                }
-                if (do_row && !col_active) S.C[swz<W>(t)] = S.row_last;  // column j0 gains row t
-                if (col_active) {
-                    double cl = S.col_last;
-                    if (do_row) {
-                        const double d = S.Dc[swz<W>(t)];
-                        const double av = dmin(S.row_last + d, S.Ac[swz<W>(t)]);
-                        cl = dmin(av, cl + d);  // cl = value of (t-1, jn), or the sentinel carry
-                        S.C[swz<W>(t)] = cl;
-                    }
-                    S.R[swz<W>(jn)] = cl;  // row t gains column jn
-                    S.cols += 1;
-                    S.cells += nc;
-                }
-                if (stop) {
-                    S.status = RTS_STOP_REF_END;
-                    S.t = t;
-                    S.j = jn;
-                    S.pending_col = 0;
-                }
+            if (!stop && deferred_update && pend_dir != -2) {  // livenote_v2.py:149-155
+                run_count = (pend_dir == prev) ? run_count + 1 : 1;
+                if (pend_dir != RTS_DIR_BOTH) prev = pend_dir;
+                pend_dir = -2;
             }
-            __builtin_amdgcn_wave_barrier();
+            if (do_row) {
+                rows += 1;
+                cells += nr;
+                consumed = pt + 1;
+            }
+            double cl = 0.0, cf_min = inf;
+            int cf_idx = 0x7fffffff;
+            if (do_row && !col_active && lane == 0) S.C[swz<W>(pt)] = row_last;  // column j0 gains row t
+            if (col_active) {
+                cl = S.col_last;
+                cf_min = S.cfresh_min;
+                cf_idx = S.cfresh_idx;
+                if (do_row) {
+                    const double d = Dc[swz<W>(pt)];
+                    const double av = vmin(row_last + d, S.Ac[swz<W>(pt)]);
+                    cl = vmin(av, cl + d);  // cl was the value of (t-1, jn), or the sentinel carry
+                    if (lane == 0) S.C[swz<W>(pt)] = cl;
+                }
+                if (lane == 0) S.R[swz<W>(jn)] = cl;  // row t gains column jn
+                cols += 1;
+                cells += nc;
+            }
             RTS_STAMP(6);
-            // row band: fresh from this step's row strip, plus the corner a column strip appended;
-            // column band: fresh from this step's column strip (its corner cell was finished by the
-            // fix-up, outside the chain), or the old band plus the row strip's last cell
-            if (!stop) decide(t, jn, do_row, col_active, col_active, do_row, false);
+            if (stop) {
+                status = RTS_STOP_REF_END;
+                t = pt;
+                j = jn;
+                pending_col = 0;
+            } else {
+                // row band: fresh from this step's row strip, plus the corner a column strip appended;
+                // column band: fresh from this step's column strip (its corner cell is outside the
+                // chain), or the old band plus the row strip's last cell
+                decide(pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl, do_row,
+                       col_active ? cl : row_last, false);
+            }
             RTS_STAMP(7);
+            make_plan();
         }
-        __syncthreads();
         RTS_STAMP(8);
-        if (S.status != RTS_RUNNING) break;
+        __syncthreads();
+        buf ^= 1;
     }
     __syncthreads();
 
     // ---- epilogue: persist bands + state
     {
-        int t = S.t, j = S.j;
-        if (t > a.live_cap - 1) t = a.live_cap - 1;
-        if (j > N - 1) j = N - 1;
+        int te = S.t, je = S.j;
+        const int t_state = te;
+        if (te > a.live_cap - 1) te = a.live_cap - 1;
+        if (je > N - 1) je = N - 1;
         double *bb = a.bands + (size_t)b * 2 * (c + 1);
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        const bool have = !S.first;
         for (int i = tid; i <= c; i += NT) {
-            const int y = j - c + i, x = t - c + i;
-            bb[i] = (have && y >= 0) ? S.R[swz<W>(y)] : qnan;
-            bb[(c + 1) + i] = (have && x >= 0 && x <= S.t) ? S.C[swz<W>(x)] : qnan;
+            const int y = je - c + i, x = te - c + i;
+            bb[i] = (y >= 0) ? S.R[swz<W>(y)] : qnan;
+            bb[(c + 1) + i] = (x >= 0 && x <= t_state) ? S.C[swz<W>(x)] : qnan;
         }
     }
 #ifdef RTS_OTW_STAMPS
@@ -736,23 +773,23 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         for (int i = 0; i < 12; i++) a.debug[(size_t)b * 16 + i] = stamp_sum[i];
 #endif
     if (tid == 0) {
-        st[RTS_ST_T] = S.t;
-        st[RTS_ST_J] = S.j;
+        st[RTS_ST_T] = t;
+        st[RTS_ST_J] = j;
         // LiveNote's set_live keeps the direction in a local; self.direction stays "both"
-        st[RTS_ST_DIRECTION] = deferred_update ? RTS_DIR_BOTH : S.dir;
-        st[RTS_ST_PREVIOUS] = S.prev;
-        st[RTS_ST_RUN_COUNT] = S.run_count;
-        st[RTS_ST_STATUS] = S.status;
-        st[RTS_ST_FIRST_INSERT] = S.first;
-        st[RTS_ST_N_PATH] = S.n_path;
-        st[RTS_ST_CONSUMED] = S.consumed;
-        st[RTS_ST_ROW_STRIPS] = S.rows;
-        st[RTS_ST_COL_STRIPS] = S.cols;
-        st[RTS_ST_CELLS_LO] = (int32_t)(uint32_t)(S.cells & 0xffffffffLL);
-        st[RTS_ST_CELLS_HI] = (int32_t)(uint32_t)((unsigned long long)S.cells >> 32);
-        st[RTS_ST_PATH_TRUNCATED] = S.truncated;
-        st[14] = S.pend_dir;
-        st[RTS_ST_BAND_RECOMPUTES] = S.recomputes;
+        st[RTS_ST_DIRECTION] = deferred_update ? RTS_DIR_BOTH : dir;
+        st[RTS_ST_PREVIOUS] = prev;
+        st[RTS_ST_RUN_COUNT] = run_count;
+        st[RTS_ST_STATUS] = status;
+        st[RTS_ST_FIRST_INSERT] = first;
+        st[RTS_ST_N_PATH] = n_path;
+        st[RTS_ST_CONSUMED] = consumed;
+        st[RTS_ST_ROW_STRIPS] = rows;
+        st[RTS_ST_COL_STRIPS] = cols;
+        st[RTS_ST_CELLS_LO] = (int32_t)(uint32_t)(cells & 0xffffffffLL);
+        st[RTS_ST_CELLS_HI] = (int32_t)(uint32_t)((unsigned long long)cells >> 32);
+        st[RTS_ST_PATH_TRUNCATED] = truncated;
+        st[14] = pend_dir;
+        st[RTS_ST_BAND_RECOMPUTES] = recomputes;
     }
 }
 
