@@ -126,7 +126,7 @@ def main():
                                    % (2 if world == 1 else 3, B, args.c, args.max_run_count, args.n_ref,
                                       frames // B, args.dtype),
                        "streams_total": B * world, "frames_per_step": total_frames,
-                       "cells_per_frame": cells / max(frames, 1), "waves_per_stream": args.waves or 4},
+                       "cells_per_frame": cells / max(frames, 1), "waves_per_stream": args.waves or 8},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": eng.kernel_name, "launch_ms": mean_launch_s * 1e3,

@@ -60,11 +60,12 @@ struct OtwLds {
     double C[SWZ];      // acc[.][j]  column band
     double Dr[2][SWZ];  // row strip cell costs: [buf] = this step's, [buf^1] = being pre-computed for the next
     double Dc[2][SWZ];
-    double Ar[SWZ];     // row strip: min over the two out-of-strip predecessors
-    double Ac[SWZ];
     double refw[kF][W];   // feature-major ring of reference frames (index y & (W-1))
     double livew[kF][W];  // feature-major ring of live frames      (index x & (W-1))
-    double col_last, cfresh_min;  // column chain wave -> wave 0
+    // column chain wave -> wave 0, read back in one go
+    double cfresh_min;
+    double corner_pa;  // Both step: acc[t-1][jn-1] + 2 d(t, jn), stashed before column jn-1 is overwritten
+    double corner_d;   // d(t, jn)
     int cfresh_idx;
     int plan_t, plan_j0, plan_flags;  // wave 0 -> everyone: the next step
     int t, j;                         // final position, published at exit for the epilogue
@@ -144,6 +145,14 @@ __device__ __forceinline__ double wave_bcast(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// A value every lane holds identically (an LDS broadcast read) -> SGPRs, so the control logic that
+// consumes it runs on the scalar unit.
+__device__ __forceinline__ double rfl(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // Minimum over the 64 lanes, returned in every lane.  Six DPP steps (row_shr 1/2/4/8, then
 // row_bcast 15 and 31) leave the total in lane 63; lanes without a DPP source keep their own value.
 #define RTS_DPP_MIN_STEP(CTRL)                                                   \
@@ -167,31 +176,56 @@ __device__ __forceinline__ double wave_min(double x) {
     return wave_bcast(x, 63);
 }
 
-// Exact solution of acc_i = min(A_i, acc_{i-1} + D_i), i in [0, n), acc_{-1} = x_in, for the strip
-// whose cell i sits at band position k1 + i.  One wave; writes out[swz(k1+i)], returns acc_{n-1}
-// (x_in if n == 0) in every lane.  Also returns np.argmin (first minimum) of the new strip
-// restricted to band positions >= lo_arg: (fmin, fidx), fidx = 0x7fffffff if that range is empty.
+// One strip, one wave.  Cell i (band position k = k1 + i, i in [0, n)) gets
+//     a_i   = min(band[k] + d_i, band[k-1] + 2 d_i)      the two predecessors outside the strip
+//                                                        (band = previous row for a row strip,
+//                                                        previous column for a column strip)
+//     acc_i = min(a_i, acc_{i-1} + d_i),  acc_{-1} = x_in the predecessor inside the strip
+// and `band` is overwritten in place with acc (the wave reads all old values before it writes).
+// Returns np.argmin (first minimum) of the new strip restricted to band positions >= lo_arg:
+// (fmin, fidx), fidx = 0x7fffffff if that range is empty.  The caller reads acc_{n-1} back from
+// band[swz(k1+n-1)].
+//
+// The recurrence is a serial float64 chain whose rounding must not change; it is solved exactly by
+// chunked speculative carry propagation (see the file header).
+//
+// Branch-free by construction.  The wave always covers W consecutive ring positions k1 .. k1+W-1;
+// cells past the strip end get d = +inf, hence acc = +inf, and are stored like the others.  That is
+// safe because those positions are exactly the ring slots *outside* the live band [k1-1, k1+n-1]
+// except k1-1 itself, which the caller rewrites with the sentinel right after, and (Both step) the
+// corner slot, which the fix-up rewrites; every band position is written with its real value
+// before it is ever read (rows/columns only grow at the top index).  Valid cells are always finite:
+// each has a computed predecessor in the previous row (row strip) or column (column strip).
 template <int W>
-__device__ __forceinline__ double strip_chain(const double *__restrict__ Dv, const double *__restrict__ Av,
-                                              double *__restrict__ out, int k1, int n, double x_in, int lane,
-                                              int lo_arg, double &fmin_out, int &fidx_out) {
+__device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, double *__restrict__ band, int k1, int n,
+                                            double x_in, int lane, int lo_arg, double &fmin_out, int &fidx_out) {
     constexpr int L = W / 64;
+    constexpr int LOG_L = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : 3;
     const double inf = INFINITY;
-    double A[L], D[L], v[L];
+    // cell (lane, m) sits at band position q + L*lane with q = k1 + m wave-uniform, i.e. at LDS slot
+    // (q mod L)*65 + ((q / L + lane) mod 64); slot[m] addresses position k - 1 of cell m
+    int slot[L + 1];
 #pragma unroll
-    for (int m = 0; m < L; m++) {
-        const int i = L * lane + m;
-        const bool valid = i < n;
-        const int s = swz<W>(k1 + i);
-        A[m] = valid ? Av[s] : inf;
-        D[m] = valid ? Dv[s] : inf;
+    for (int m = 0; m <= L; m++) {
+        const int q = k1 + m - 1 + W;  // + W keeps q >= 0 without changing the slot
+        slot[m] = (q & (L - 1)) * 65 + (((q >> LOG_L) + lane) & 63);
     }
+    const int nloc = n - L * lane;  // cell m of this lane is inside the strip iff m < nloc
+    double prevb[L + 1], D[L], v[L];
+#pragma unroll
+    for (int m = 0; m <= L; m++) prevb[m] = band[slot[m]];  // positions k-1 .. k+L-1
+#pragma unroll
+    for (int m = 0; m < L; m++) D[m] = Dv[slot[m + 1]];
+    prevb[0] = (k1 == 0 && lane == 0) ? inf : prevb[0];  // row/column 0 has no diagonal predecessor
+#pragma unroll
+    for (int m = 0; m < L; m++) D[m] = (m < nloc) ? D[m] : inf;
     // round 0: every lane scans its own cells; only lane 0 knows its true carry-in
     double p = (lane == 0) ? x_in : inf;
 #pragma unroll
     for (int m = 0; m < L; m++) {
+        const double am = vmin(prevb[m + 1] + D[m], prevb[m] + 2 * D[m]);
         p = p + D[m];
-        v[m] = vmin(A[m], p);
+        v[m] = vmin(am, p);
         p = v[m];
     }
     // further rounds: carry-in = left neighbour's current last value.  Values only ever decrease
@@ -212,32 +246,23 @@ __device__ __forceinline__ double strip_chain(const double *__restrict__ Dv, con
             v[m] = vmin(v[m], q);
         }
     }
-    double lm = inf;
 #pragma unroll
-    for (int m = 0; m < L; m++) {
-        const int i = L * lane + m;
-        if (i < n) {
-            out[swz<W>(k1 + i)] = v[m];
-            if (k1 + i >= lo_arg) lm = vmin(lm, v[m]);
-        }
-    }
-    // first minimum: lowest lane holding the wave minimum, then its first matching cell
+    for (int m = 0; m < L; m++) band[slot[m + 1]] = v[m];
+    // first minimum over positions >= lo_arg: lo_arg is k1 or k1 + 1, so at most the very first
+    // cell is excluded
+    const double v0 = (lane == 0 && lo_arg > k1) ? inf : v[0];
+    double lm = v0;
+#pragma unroll
+    for (int m = 1; m < L; m++) lm = vmin(lm, v[m]);
     const double g = wave_min(lm);
     int cand = 0x7fffffff;
 #pragma unroll
-    for (int m = L - 1; m >= 0; m--) {
-        const int i = L * lane + m;
-        if (i < n && k1 + i >= lo_arg && v[m] == g) cand = k1 + i;
-    }
+    for (int m = L - 1; m >= 1; m--) cand = (v[m] == g) ? k1 + L * lane + m : cand;
+    cand = (v0 == g) ? k1 + L * lane : cand;
     const unsigned long long mask = __ballot(cand != 0x7fffffff);
+    const bool some = (g < inf) && (mask != 0);
     fmin_out = g;
-    fidx_out = mask ? __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(mask)) : 0x7fffffff;
-    if (n == 0) return x_in;
-    const int li = n - 1;
-    double mine = v[0];
-#pragma unroll
-    for (int m = 1; m < L; m++) mine = ((li % L) == m) ? v[m] : mine;
-    return wave_bcast(mine, li / L);
+    fidx_out = some ? __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(mask | (1ull << 63))) : 0x7fffffff;
 }
 
 // np.argmin over band[lo..hi] (first minimum); (inf, 0x7fffffff) for an empty range.  One wave;
@@ -282,6 +307,246 @@ __device__ __forceinline__ void band_argmin(const double *__restrict__ band, int
     } while (0)
 #endif
 
+// ---- control state of one stream.  Lives in wave 0's registers (every lane identical) for the whole
+// launch; the other waves only ever see the 3-word plan in LDS.
+struct OtwCtl {
+    int t, j, dir, prev, run_count, status, first, n_path, consumed, rows, cols, truncated, pend_dir;
+    int recomputes, pending_col, last_x, last_y, rb_idx, cb_idx;
+    int live_hi, ref_hi;  // highest frame index present in the live / reference ring
+    long long cells;
+    double rb_min, cb_min;          // np.argmin state of the two bands at the last decide()
+    double pfl0, pfl1, pfr0, pfr1;  // prefetched ring frames (two values per lane of wave 0)
+};
+
+struct OtwEnv {  // launch-invariant values every helper needs
+    int b, lane, c, N, live_len, live_cap, euclid, variant, mode, max_run_count, path_cap, live_f64, ref_f64;
+    long long live_base;
+    const void *live, *ref;
+    int32_t *path;
+    bool deferred_update;
+};
+
+constexpr int kPlanRow = 1, kPlanCol = 2, kPlanStop = 4, kPlanExit = 8;
+
+__device__ __forceinline__ double otw_load_feat(const void *base, int is_f64, long long idx) {
+    return is_f64 ? reinterpret_cast<const double *>(base)[idx] : (double)reinterpret_cast<const float *>(base)[idx];
+}
+
+// Asynchronous ring refills (wave 0): the next kFetch frames sit in two registers per lane, loaded a
+// refill period (~8 steps) before they are written into the ring.
+__device__ __forceinline__ void otw_prefetch_live(OtwCtl &k, const OtwEnv &e) {
+    const int i0 = e.lane, i1 = e.lane + 64;
+    const int f0 = k.live_hi + 1 + i0 / kF, f1 = k.live_hi + 1 + i1 / kF;
+    if (f0 < e.live_len) k.pfl0 = otw_load_feat(e.live, e.live_f64, e.live_base + (long long)f0 * kF + i0 % kF);
+    if (i1 < kFetch * kF && f1 < e.live_len)
+        k.pfl1 = otw_load_feat(e.live, e.live_f64, e.live_base + (long long)f1 * kF + i1 % kF);
+}
+__device__ __forceinline__ void otw_prefetch_ref(OtwCtl &k, const OtwEnv &e) {
+    const int i0 = e.lane, i1 = e.lane + 64;
+    const int f0 = k.ref_hi + 1 + i0 / kF, f1 = k.ref_hi + 1 + i1 / kF;
+    if (f0 < e.N) k.pfr0 = otw_load_feat(e.ref, e.ref_f64, (long long)f0 * kF + i0 % kF);
+    if (i1 < kFetch * kF && f1 < e.N) k.pfr1 = otw_load_feat(e.ref, e.ref_f64, (long long)f1 * kF + i1 % kF);
+}
+template <int W>
+__device__ __forceinline__ void otw_commit_live(OtwLds<W> &S, OtwCtl &k, const OtwEnv &e) {
+    const int i0 = e.lane, i1 = e.lane + 64;
+    const int f0 = k.live_hi + 1 + i0 / kF, f1 = k.live_hi + 1 + i1 / kF;
+    if (f0 < e.live_len) S.livew[i0 % kF][f0 & (W - 1)] = k.pfl0;
+    if (i1 < kFetch * kF && f1 < e.live_len) S.livew[i1 % kF][f1 & (W - 1)] = k.pfl1;
+    k.live_hi = (k.live_hi + kFetch < e.live_len - 1) ? k.live_hi + kFetch : e.live_len - 1;
+    otw_prefetch_live(k, e);
+}
+template <int W>
+__device__ __forceinline__ void otw_commit_ref(OtwLds<W> &S, OtwCtl &k, const OtwEnv &e) {
+    const int i0 = e.lane, i1 = e.lane + 64;
+    const int f0 = k.ref_hi + 1 + i0 / kF, f1 = k.ref_hi + 1 + i1 / kF;
+    if (f0 < e.N) S.refw[i0 % kF][f0 & (W - 1)] = k.pfr0;
+    if (i1 < kFetch * kF && f1 < e.N) S.refw[i1 % kF][f1 & (W - 1)] = k.pfr1;
+    k.ref_hi = (k.ref_hi + kFetch < e.N - 1) ? k.ref_hi + kFetch : e.N - 1;
+    otw_prefetch_ref(k, e);
+}
+
+// Speculative costs for the step after the one that leaves the state at (t_now, j_now): row t_now+1
+// over columns [j_now-c+1, j_now] and column j_now+1 over rows [t_now-c+1, t_now+1] cover every
+// possible next step (Row, Both or Column).  hidx / hn: index and count of the threads sharing it.
+template <int W>
+__device__ __forceinline__ void otw_precompute(OtwLds<W> &S, const OtwEnv &e, int t_now, int j_now, double *Drn,
+                                               double *Dcn, int hidx, int hn) {
+    const int c = e.c;
+    const int tn = t_now + 1, jn1 = j_now + 1;
+    const bool row_ok = (tn < e.live_len) && (tn < e.live_cap);
+    const bool col_ok = jn1 < e.N;
+    const int k1 = (j_now - c + 1 > 0) ? j_now - c + 1 : 0;
+    const int nrow = row_ok ? j_now - k1 + 1 : 0;
+    const int r1 = (t_now - c + 1 > 0) ? t_now - c + 1 : 0;
+    const int rtop = row_ok ? tn : t_now;
+    const int ncol = col_ok ? rtop - r1 + 1 : 0;
+    if (nrow > 0) {
+        double lf[kF];
+#pragma unroll
+        for (int f = 0; f < kF; f++) lf[f] = S.livew[f][tn & (W - 1)];
+        for (int i = hidx; i < nrow; i += hn) {
+            const int k = k1 + i;
+            double rf[kF];
+#pragma unroll
+            for (int f = 0; f < kF; f++) rf[f] = S.refw[f][k & (W - 1)];
+            Drn[swz<W>(k)] = cell_cost(lf, rf, e.euclid);
+        }
+    }
+    if (ncol > 0) {
+        double rf[kF];
+#pragma unroll
+        for (int f = 0; f < kF; f++) rf[f] = S.refw[f][jn1 & (W - 1)];
+        for (int i = hidx; i < ncol; i += hn) {
+            const int r = r1 + i;
+            double lf[kF];
+#pragma unroll
+            for (int f = 0; f < kF; f++) lf[f] = S.livew[f][r & (W - 1)];
+            Dcn[swz<W>(r)] = cell_cost(lf, rf, e.euclid);
+        }
+    }
+}
+
+// decide(): best_point + path + direction (otw_eran.py:153-211, livenote_v2.py:193-236).  Wave 0,
+// all lanes, register state.  The two band argmins are kept incrementally: a strip computed this
+// step brings its own argmin from its chain; a band that merely slid by one cell keeps its minimum
+// unless that cell left the window (then a full wave reduction recomputes it); the one cell
+// appended at the top index wins only if strictly smaller (np.argmin returns the first minimum).
+template <int W>
+__device__ __forceinline__ void otw_decide(OtwLds<W> &S, OtwCtl &k, const OtwEnv &e, int tt, int jj, bool row_fresh,
+                                           double rf_min, int rf_idx, bool col_fresh, double cf_min, int cf_idx,
+                                           bool row_corner, double rc, bool col_corner, double cc, bool full) {
+    const int c = e.c;
+    const int j1 = (jj - c + 1 > 0) ? jj - c + 1 : 0;
+    const int t1 = (tt - c + 1 > 0) ? tt - c + 1 : 0;
+    double rmin, cmin;
+    int ridx, cidx;
+    if (full) {
+        band_argmin<W>(S.R, j1, jj, e.lane, rmin, ridx);
+        band_argmin<W>(S.C, t1, tt, e.lane, cmin, cidx);
+    } else {
+        if (row_fresh) {
+            rmin = rf_min;
+            ridx = rf_idx;
+        } else {
+            rmin = k.rb_min;
+            ridx = k.rb_idx;
+            if (ridx < j1) {  // the old minimum slid out of the window
+                band_argmin<W>(S.R, j1, row_corner ? jj - 1 : jj, e.lane, rmin, ridx);
+                k.recomputes += 1;
+            }
+        }
+        if (row_corner && rc < rmin) {
+            rmin = rc;
+            ridx = jj;
+        }
+        if (col_fresh) {
+            cmin = cf_min;
+            cidx = cf_idx;
+        } else {
+            cmin = k.cb_min;
+            cidx = k.cb_idx;
+            if (cidx < t1) {
+                band_argmin<W>(S.C, t1, col_corner ? tt - 1 : tt, e.lane, cmin, cidx);
+                k.recomputes += 1;
+            }
+        }
+        if (col_corner && cc < cmin) {
+            cmin = cc;
+            cidx = tt;
+        }
+    }
+    k.rb_min = rmin;
+    k.rb_idx = ridx;
+    k.cb_min = cmin;
+    k.cb_idx = cidx;
+    int x, y;
+    if (rmin < cmin) {
+        x = tt;
+        y = ridx;
+    } else {
+        x = cidx;
+        y = jj;
+    }
+    bool append = true;
+    if (e.variant == RTS_VARIANT_LIVENOTE_V2)  // livenote_v2.py:198
+        append = (k.n_path == 0) || (x > k.last_x && y >= k.last_y);
+    if (append) {
+        if (k.n_path < e.path_cap) {
+            if (e.lane == 0) {
+                int2 *pp = reinterpret_cast<int2 *>(e.path) + ((size_t)e.b * e.path_cap + k.n_path);
+                *pp = make_int2(x, y);
+            }
+        } else {
+            k.truncated = 1;
+        }
+        k.n_path += 1;
+        k.last_x = x;
+        k.last_y = y;
+    }
+    int nd;
+    if (tt < c)
+        nd = RTS_DIR_BOTH;
+    else if (k.run_count >= e.max_run_count)
+        nd = (k.prev == RTS_DIR_ROW) ? RTS_DIR_COLUMN : RTS_DIR_ROW;
+    else if (x < tt)
+        nd = RTS_DIR_COLUMN;
+    else if (y < jj)
+        nd = RTS_DIR_ROW;
+    else
+        nd = RTS_DIR_BOTH;
+    if (e.deferred_update) {
+        k.pend_dir = nd;
+    } else {
+        k.run_count = (nd == k.prev) ? k.run_count + 1 : 1;
+        if (nd != RTS_DIR_BOTH) k.prev = nd;
+    }
+    k.dir = nd;
+    k.pending_col = (nd == RTS_DIR_COLUMN);
+    k.t = tt;
+    k.j = jj;
+}
+
+// Plan for the next step from the current register state (wave 0); lane 0 publishes it.
+template <int W>
+__device__ __forceinline__ void otw_make_plan(OtwLds<W> &S, OtwCtl &k, const OtwEnv &e) {
+    int flags = 0, pt = k.t;
+    if (k.status != RTS_RUNNING) {
+        flags = kPlanExit;
+    } else if (k.pending_col) {
+        flags = kPlanCol;
+    } else if (k.t + 1 >= e.live_len) {  // live sequence exhausted
+        if (e.mode == RTS_MODE_SET_LIVE) k.t = k.t + 1;  // otw_eran.py:111-115
+        flags = kPlanExit;
+    } else if (k.t + 1 >= e.live_cap) {  // otw_eran.py:53-55
+        k.status = RTS_LIVE_OVERFLOW;
+        k.t = e.live_len - 1;
+        k.consumed = e.live_len;
+        flags = kPlanExit;
+    } else {
+        pt = k.t + 1;
+        flags = kPlanRow | ((k.dir != RTS_DIR_ROW) ? kPlanCol : 0);
+    }
+    if ((flags & kPlanCol) && k.j + 1 >= e.N) flags |= kPlanStop;  // otw_eran.py:67-71
+    if (e.lane == 0) {
+        S.plan_t = pt;
+        S.plan_j0 = k.j;
+        S.plan_flags = flags;
+        if (flags & kPlanExit) {
+            S.t = k.t;
+            S.j = k.j;
+        }
+    }
+    // keep the rings one frame ahead of what this step's cost pre-computation will read
+    if (!(flags & kPlanExit)) {
+        const int jn_p = k.j + ((flags & kPlanCol) ? 1 : 0);
+        const int need_l = (pt + 1 < e.live_len - 1) ? pt + 1 : e.live_len - 1;
+        const int need_r = (jn_p + 1 < e.N - 1) ? jn_p + 1 : e.N - 1;
+        if (need_l > k.live_hi) otw_commit_live<W>(S, k, e);
+        if (need_r > k.ref_hi) otw_commit_ref<W>(S, k, e);
+    }
+}
+
 template <int W, int NW>
 __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     constexpr int NT = 64 * NW;
@@ -289,7 +554,6 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     // than 4 waves there are no spare ones and every wave does its share after its chain.
     constexpr int HW0 = (NW >= 4) ? 2 : 0;
     constexpr int NHELP = 64 * (NW - HW0);
-    constexpr int kPlanRow = 1, kPlanCol = 2, kPlanStop = 4, kPlanExit = 8;
 #ifdef RTS_OTW_STAMPS
     long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long stamp_last = (long long)__builtin_amdgcn_s_memtime();
@@ -298,346 +562,158 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     OtwLds<W> &S = *reinterpret_cast<OtwLds<W> *>(smem_raw);
 
-    const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int c = a.c, N = a.N;
-    const int euclid = a.cost_kind == RTS_COST_EUCLID;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform -> scalar branches
     const double sentinel = (a.variant == RTS_VARIANT_OTW) ? 1e10 : (double)INFINITY;
     const double inf = INFINITY;
-    int32_t *st = a.state + (size_t)b * RTS_STATE_LEN;
-    int live_len_raw = a.live_len[b];
+    OtwEnv e;
+    e.b = blockIdx.x;
+    e.lane = lane;
+    e.c = a.c;
+    e.N = a.N;
+    e.live_cap = a.live_cap;
+    e.euclid = a.cost_kind == RTS_COST_EUCLID;
+    e.variant = a.variant;
+    e.mode = a.mode;
+    e.max_run_count = a.max_run_count;
+    e.path_cap = a.path_cap;
+    e.live_f64 = a.live_f64;
+    e.ref_f64 = a.ref_f64;
+    e.live_base = (long long)e.b * a.live_stride * kF;
+    e.live = a.live;
+    e.ref = a.ref;
+    e.path = a.path;
+    // LiveNote's set_live applies the run-count update at the bottom of its loop (livenote_v2.py:149-155)
+    e.deferred_update = (a.mode == RTS_MODE_SET_LIVE) && (a.variant != RTS_VARIANT_OTW);
+    const int c = a.c, N = a.N;
+    int32_t *st = a.state + (size_t)e.b * RTS_STATE_LEN;
+    int live_len_raw = a.live_len[e.b];
     if (a.clamp_len && live_len_raw > (int)a.live_stride) live_len_raw = (int)a.live_stride;
     if (live_len_raw < 0) live_len_raw = 0;
-    const int live_len = live_len_raw;
-    // LiveNote's set_live applies the run-count update at the bottom of its loop (livenote_v2.py:149-155)
-    const bool deferred_update = (a.mode == RTS_MODE_SET_LIVE) && (a.variant != RTS_VARIANT_OTW);
+    e.live_len = live_len_raw;
+    const int live_len = e.live_len;
 
-    // ---- control state.  Every thread loads it (uniform), but only wave 0 keeps it current: it lives
-    // in wave 0's registers for the whole launch and reaches the other waves as a 3-word plan in LDS.
-    int t = st[RTS_ST_T], j = st[RTS_ST_J], dir = st[RTS_ST_DIRECTION], prev = st[RTS_ST_PREVIOUS];
-    int run_count = st[RTS_ST_RUN_COUNT], status = st[RTS_ST_STATUS], first = st[RTS_ST_FIRST_INSERT];
-    int n_path = st[RTS_ST_N_PATH], consumed = st[RTS_ST_CONSUMED], rows = st[RTS_ST_ROW_STRIPS];
-    int cols = st[RTS_ST_COL_STRIPS], truncated = st[RTS_ST_PATH_TRUNCATED], pend_dir = st[14];
-    int recomputes = st[RTS_ST_BAND_RECOMPUTES];
-    long long cells = ((long long)(uint32_t)st[RTS_ST_CELLS_HI] << 32) | (uint32_t)st[RTS_ST_CELLS_LO];
-    int pending_col = 0, last_x = -1, last_y = -1;
-    if (n_path > 0 && n_path <= a.path_cap) {
-        const int32_t *pp = a.path + ((size_t)b * a.path_cap + (n_path - 1)) * 2;
-        last_x = pp[0];
-        last_y = pp[1];
+    // every thread loads the state (uniform scalar loads); only wave 0 keeps it current
+    OtwCtl k;
+    k.t = st[RTS_ST_T];
+    k.j = st[RTS_ST_J];
+    k.dir = st[RTS_ST_DIRECTION];
+    k.prev = st[RTS_ST_PREVIOUS];
+    k.run_count = st[RTS_ST_RUN_COUNT];
+    k.status = st[RTS_ST_STATUS];
+    k.first = st[RTS_ST_FIRST_INSERT];
+    k.n_path = st[RTS_ST_N_PATH];
+    k.consumed = st[RTS_ST_CONSUMED];
+    k.rows = st[RTS_ST_ROW_STRIPS];
+    k.cols = st[RTS_ST_COL_STRIPS];
+    k.truncated = st[RTS_ST_PATH_TRUNCATED];
+    k.pend_dir = st[14];
+    k.recomputes = st[RTS_ST_BAND_RECOMPUTES];
+    k.cells = ((long long)(uint32_t)st[RTS_ST_CELLS_HI] << 32) | (uint32_t)st[RTS_ST_CELLS_LO];
+    k.pending_col = 0;
+    k.last_x = -1;
+    k.last_y = -1;
+    if (k.n_path > 0 && k.n_path <= a.path_cap) {
+        const int32_t *pp = a.path + ((size_t)e.b * a.path_cap + (k.n_path - 1)) * 2;
+        k.last_x = pp[0];
+        k.last_y = pp[1];
     }
-    double rb_min = inf, cb_min = inf;
-    int rb_idx = 0, cb_idx = 0;
+    k.rb_min = inf;
+    k.cb_min = inf;
+    k.rb_idx = 0;
+    k.cb_idx = 0;
+    k.pfl0 = k.pfl1 = k.pfr0 = k.pfr1 = 0.0;
 
-    if (status == RTS_STOP_REF_END) return;  // sticky; the reference's callers stop inserting
-    if (status == RTS_LIVE_OVERFLOW) {       // otw_eran.py:50-55: t keeps counting inserts
-        if (tid == 0 && live_len > consumed) {
+    if (k.status == RTS_STOP_REF_END) return;  // sticky; the reference's callers stop inserting
+    if (k.status == RTS_LIVE_OVERFLOW) {       // otw_eran.py:50-55: t keeps counting inserts
+        if (tid == 0 && live_len > k.consumed) {
             st[RTS_ST_T] = live_len - 1;
             st[RTS_ST_CONSUMED] = live_len;
         }
         return;
     }
-    if (live_len <= consumed) return;  // nothing new
+    if (live_len <= k.consumed) return;  // nothing new
 
-    // ---- feature rings
-    auto load_feat = [&](const void *base, int is_f64, long long idx) -> double {
-        return is_f64 ? reinterpret_cast<const double *>(base)[idx]
-                      : (double)reinterpret_cast<const float *>(base)[idx];
-    };
-    const long long live_base = (long long)b * a.live_stride * kF;
-    auto fill_live = [&](int lo, int hi) {  // synchronous, all threads (prologue only)
-        for (int idx = tid; idx < (hi - lo + 1) * kF; idx += NT) {
-            const int fr = lo + idx / kF, f = idx % kF;
-            S.livew[f][fr & (W - 1)] = load_feat(a.live, a.live_f64, live_base + (long long)fr * kF + f);
-        }
-    };
-    auto fill_ref = [&](int lo, int hi) {
-        for (int idx = tid; idx < (hi - lo + 1) * kF; idx += NT) {
-            const int fr = lo + idx / kF, f = idx % kF;
-            S.refw[f][fr & (W - 1)] = load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
-        }
-    };
-    // Asynchronous refills (wave 0): the next kFetch frames sit in two registers per lane, loaded a
-    // refill period (~8 steps) before they are written into the ring.
-    int live_hi = -1, ref_hi = -1;
-    double pfl0 = 0.0, pfl1 = 0.0, pfr0 = 0.0, pfr1 = 0.0;
-    auto prefetch_live = [&]() {  // frames live_hi+1 .. live_hi+kFetch
-        const int i0 = lane, i1 = lane + 64;
-        const int f0 = live_hi + 1 + i0 / kF, f1 = live_hi + 1 + i1 / kF;
-        if (f0 < live_len) pfl0 = load_feat(a.live, a.live_f64, live_base + (long long)f0 * kF + i0 % kF);
-        if (i1 < kFetch * kF && f1 < live_len)
-            pfl1 = load_feat(a.live, a.live_f64, live_base + (long long)f1 * kF + i1 % kF);
-    };
-    auto prefetch_ref = [&]() {
-        const int i0 = lane, i1 = lane + 64;
-        const int f0 = ref_hi + 1 + i0 / kF, f1 = ref_hi + 1 + i1 / kF;
-        if (f0 < N) pfr0 = load_feat(a.ref, a.ref_f64, (long long)f0 * kF + i0 % kF);
-        if (i1 < kFetch * kF && f1 < N) pfr1 = load_feat(a.ref, a.ref_f64, (long long)f1 * kF + i1 % kF);
-    };
-    auto commit_live = [&]() {  // registers -> ring, then start fetching the following block
-        const int i0 = lane, i1 = lane + 64;
-        const int f0 = live_hi + 1 + i0 / kF, f1 = live_hi + 1 + i1 / kF;
-        if (f0 < live_len) S.livew[i0 % kF][f0 & (W - 1)] = pfl0;
-        if (i1 < kFetch * kF && f1 < live_len) S.livew[i1 % kF][f1 & (W - 1)] = pfl1;
-        live_hi = (live_hi + kFetch < live_len - 1) ? live_hi + kFetch : live_len - 1;
-        prefetch_live();
-    };
-    auto commit_ref = [&]() {
-        const int i0 = lane, i1 = lane + 64;
-        const int f0 = ref_hi + 1 + i0 / kF, f1 = ref_hi + 1 + i1 / kF;
-        if (f0 < N) S.refw[i0 % kF][f0 & (W - 1)] = pfr0;
-        if (i1 < kFetch * kF && f1 < N) S.refw[i1 % kF][f1 & (W - 1)] = pfr1;
-        ref_hi = (ref_hi + kFetch < N - 1) ? ref_hi + kFetch : N - 1;
-        prefetch_ref();
-    };
-
-    // ---- speculative costs for the step after the one that leaves the state at (t_now, j_now):
-    // row t_now+1 over columns [j_now-c+1, j_now] and column j_now+1 over rows [t_now-c+1, t_now+1]
-    // cover every possible next step (Row, Both or Column).  hidx/hn: index and count of the
-    // threads sharing the work.
-    auto precompute = [&](int t_now, int j_now, double *Drn, double *Dcn, int hidx, int hn) {
-        const int tn = t_now + 1, jn1 = j_now + 1;
-        const bool row_ok = (tn < live_len) && (tn < a.live_cap);
-        const bool col_ok = jn1 < N;
-        const int k1 = (j_now - c + 1 > 0) ? j_now - c + 1 : 0;
-        const int nrow = row_ok ? j_now - k1 + 1 : 0;
-        const int r1 = (t_now - c + 1 > 0) ? t_now - c + 1 : 0;
-        const int rtop = row_ok ? tn : t_now;
-        const int ncol = col_ok ? rtop - r1 + 1 : 0;
-        if (nrow > 0) {
-            double lf[kF];
-#pragma unroll
-            for (int f = 0; f < kF; f++) lf[f] = S.livew[f][tn & (W - 1)];
-            for (int i = hidx; i < nrow; i += hn) {
-                const int k = k1 + i;
-                double rf[kF];
-#pragma unroll
-                for (int f = 0; f < kF; f++) rf[f] = S.refw[f][k & (W - 1)];
-                Drn[swz<W>(k)] = cell_cost(lf, rf, euclid);
-            }
-        }
-        if (ncol > 0) {
-            double rf[kF];
-#pragma unroll
-            for (int f = 0; f < kF; f++) rf[f] = S.refw[f][jn1 & (W - 1)];
-            for (int i = hidx; i < ncol; i += hn) {
-                const int r = r1 + i;
-                double lf[kF];
-#pragma unroll
-                for (int f = 0; f < kF; f++) lf[f] = S.livew[f][r & (W - 1)];
-                Dcn[swz<W>(r)] = cell_cost(lf, rf, euclid);
-            }
-        }
-    };
-
-    // ---- decide(): best_point + path + direction (otw_eran.py:153-211, livenote_v2.py:193-236).
-    // Wave 0, all lanes, register state.  The two band argmins are kept incrementally: a strip
-    // computed this step brings its own argmin from its chain; a band that merely slid by one cell
-    // keeps its minimum unless that cell left the window (then a full wave reduction recomputes
-    // it); the one cell appended at the top index wins only if strictly smaller (np.argmin returns
-    // the first minimum).
-    auto decide = [&](int tt, int jj, bool row_fresh, double rf_min, int rf_idx, bool col_fresh, double cf_min,
-                      int cf_idx, bool row_corner, double rc, bool col_corner, double cc, bool full) {
-        const int j1 = (jj - c + 1 > 0) ? jj - c + 1 : 0;
-        const int t1 = (tt - c + 1 > 0) ? tt - c + 1 : 0;
-        double rmin, cmin;
-        int ridx, cidx;
-        if (full) {
-            band_argmin<W>(S.R, j1, jj, lane, rmin, ridx);
-            band_argmin<W>(S.C, t1, tt, lane, cmin, cidx);
-        } else {
-            if (row_fresh) {
-                rmin = rf_min;
-                ridx = rf_idx;
-            } else {
-                rmin = rb_min;
-                ridx = rb_idx;
-                if (ridx < j1) {  // the old minimum slid out of the window
-                    band_argmin<W>(S.R, j1, row_corner ? jj - 1 : jj, lane, rmin, ridx);
-                    recomputes += 1;
-                }
-            }
-            if (row_corner && rc < rmin) {
-                rmin = rc;
-                ridx = jj;
-            }
-            if (col_fresh) {
-                cmin = cf_min;
-                cidx = cf_idx;
-            } else {
-                cmin = cb_min;
-                cidx = cb_idx;
-                if (cidx < t1) {
-                    band_argmin<W>(S.C, t1, col_corner ? tt - 1 : tt, lane, cmin, cidx);
-                    recomputes += 1;
-                }
-            }
-            if (col_corner && cc < cmin) {
-                cmin = cc;
-                cidx = tt;
-            }
-        }
-        rb_min = rmin;
-        rb_idx = ridx;
-        cb_min = cmin;
-        cb_idx = cidx;
-        int x, y;
-        if (rmin < cmin) {
-            x = tt;
-            y = ridx;
-        } else {
-            x = cidx;
-            y = jj;
-        }
-        bool append = true;
-        if (a.variant == RTS_VARIANT_LIVENOTE_V2)  // livenote_v2.py:198
-            append = (n_path == 0) || (x > last_x && y >= last_y);
-        if (append) {
-            if (n_path < a.path_cap) {
-                if (lane == 0) {
-                    int2 *pp = reinterpret_cast<int2 *>(a.path) + ((size_t)b * a.path_cap + n_path);
-                    *pp = make_int2(x, y);
-                }
-            } else {
-                truncated = 1;
-            }
-            n_path += 1;
-            last_x = x;
-            last_y = y;
-        }
-        int nd;
-        if (tt < c)
-            nd = RTS_DIR_BOTH;
-        else if (run_count >= a.max_run_count)
-            nd = (prev == RTS_DIR_ROW) ? RTS_DIR_COLUMN : RTS_DIR_ROW;
-        else if (x < tt)
-            nd = RTS_DIR_COLUMN;
-        else if (y < jj)
-            nd = RTS_DIR_ROW;
-        else
-            nd = RTS_DIR_BOTH;
-        if (deferred_update) {
-            pend_dir = nd;
-        } else {
-            run_count = (nd == prev) ? run_count + 1 : 1;
-            if (nd != RTS_DIR_BOTH) prev = nd;
-        }
-        dir = nd;
-        pending_col = (nd == RTS_DIR_COLUMN);
-        t = tt;
-        j = jj;
-    };
-
-    // ---- plan for the next step from the current register state (wave 0); lane 0 publishes it
-    auto make_plan = [&]() {
-        int flags = 0, pt = t;
-        if (status != RTS_RUNNING) {
-            flags = kPlanExit;
-        } else if (pending_col) {
-            flags = kPlanCol;
-        } else if (t + 1 >= live_len) {  // live sequence exhausted
-            if (a.mode == RTS_MODE_SET_LIVE) t = t + 1;  // otw_eran.py:111-115
-            flags = kPlanExit;
-        } else if (t + 1 >= a.live_cap) {  // otw_eran.py:53-55
-            status = RTS_LIVE_OVERFLOW;
-            t = live_len - 1;
-            consumed = live_len;
-            flags = kPlanExit;
-        } else {
-            pt = t + 1;
-            flags = kPlanRow | ((dir != RTS_DIR_ROW) ? kPlanCol : 0);
-        }
-        if ((flags & kPlanCol) && j + 1 >= N) flags |= kPlanStop;  // otw_eran.py:67-71
-        if (lane == 0) {
-            S.plan_t = pt;
-            S.plan_j0 = j;
-            S.plan_flags = flags;
-            if (flags & kPlanExit) {
-                S.t = t;
-                S.j = j;
-            }
-        }
-        // keep the rings one frame ahead of what this step's cost pre-computation will read
-        if (!(flags & kPlanExit)) {
-            const int jn_p = j + ((flags & kPlanCol) ? 1 : 0);
-            const int need_l = (pt + 1 < live_len - 1) ? pt + 1 : live_len - 1;
-            const int need_r = (jn_p + 1 < N - 1) ? jn_p + 1 : N - 1;
-            if (need_l > live_hi) commit_live();
-            if (need_r > ref_hi) commit_ref();
-        }
-    };
-
-    // ---- prologue: first frame, or reload of the persisted bands / windows
+    // ---- prologue: windows (synchronous fill by all threads), persisted bands, first frame
+    for (int i = tid; i < OtwLds<W>::SWZ; i += NT) {  // no uninitialised LDS ever reaches the arithmetic
+        S.R[i] = 0.0;
+        S.C[i] = 0.0;
+        S.Dr[0][i] = S.Dr[1][i] = S.Dc[0][i] = S.Dc[1][i] = 0.0;
+    }
+    __syncthreads();
     {
-        const int lo_l = (t - c + 1 > 0) ? t - c + 1 : 0;
-        const int lo_r = (j - c + 1 > 0) ? j - c + 1 : 0;
-        live_hi = (t + 2 < live_len - 1) ? t + 2 : live_len - 1;
-        ref_hi = (j + 2 < N - 1) ? j + 2 : N - 1;
-        fill_live(lo_l, live_hi);
-        fill_ref(lo_r, ref_hi);
-        if (!first) {
-            const double *bb = a.bands + (size_t)b * 2 * (c + 1);
+        const int lo_l = (k.t - c + 1 > 0) ? k.t - c + 1 : 0;
+        const int lo_r = (k.j - c + 1 > 0) ? k.j - c + 1 : 0;
+        k.live_hi = (k.t + 2 < live_len - 1) ? k.t + 2 : live_len - 1;
+        k.ref_hi = (k.j + 2 < N - 1) ? k.j + 2 : N - 1;
+        for (int idx = tid; idx < (k.live_hi - lo_l + 1) * kF; idx += NT) {
+            const int fr = lo_l + idx / kF, f = idx % kF;
+            S.livew[f][fr & (W - 1)] = otw_load_feat(a.live, a.live_f64, e.live_base + (long long)fr * kF + f);
+        }
+        for (int idx = tid; idx < (k.ref_hi - lo_r + 1) * kF; idx += NT) {
+            const int fr = lo_r + idx / kF, f = idx % kF;
+            S.refw[f][fr & (W - 1)] = otw_load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
+        }
+        if (!k.first) {
+            const double *bb = a.bands + (size_t)e.b * 2 * (c + 1);
             for (int i = tid; i <= c; i += NT) {
-                const int y = j - c + i, x = t - c + i;
+                const int y = k.j - c + i, x = k.t - c + i;
                 if (y >= 0) S.R[swz<W>(y)] = bb[i];
                 if (x >= 0) S.C[swz<W>(x)] = bb[(c + 1) + i];
             }
         }
         __syncthreads();
-        if (wave == 0) {
-            prefetch_live();
-            prefetch_ref();
-        }
     }
-    if (first) {
-        if (wave == 0) {
+    if (wave == 0) {
+        otw_prefetch_live(k, e);
+        otw_prefetch_ref(k, e);
+        if (k.first) {
             double lf[kF], rf[kF];
 #pragma unroll
             for (int f = 0; f < kF; f++) {
                 lf[f] = S.livew[f][0];
                 rf[f] = S.refw[f][0];
             }
-            const double d = cell_cost(lf, rf, euclid);
+            const double d = rfl(cell_cost(lf, rf, e.euclid));
             if (lane == 0) {
                 S.R[swz<W>(0)] = d;
                 S.C[swz<W>(0)] = d;
             }
-            first = 0;
-            consumed = 1;
-            cells += 1;
-            t = 0;
-            j = 0;
-            pend_dir = -2;
-            rb_min = d;
-            cb_min = d;
-            rb_idx = 0;
-            cb_idx = 0;
+            k.first = 0;
+            k.consumed = 1;
+            k.cells += 1;
+            k.t = 0;
+            k.j = 0;
+            k.pend_dir = -2;
+            k.rb_min = d;
+            k.cb_min = d;
+            k.rb_idx = 0;
+            k.cb_idx = 0;
             __builtin_amdgcn_wave_barrier();
-            if (a.mode == RTS_MODE_SET_LIVE) decide(0, 0, false, 0.0, 0, false, 0.0, 0, false, 0.0, false, 0.0, true);
+            if (a.mode == RTS_MODE_SET_LIVE)
+                otw_decide<W>(S, k, e, 0, 0, false, 0.0, 0, false, 0.0, 0, false, 0.0, false, 0.0, true);
+        } else {  // band minima are not persisted: rebuild them from the reloaded bands
+            band_argmin<W>(S.R, (k.j - c + 1 > 0) ? k.j - c + 1 : 0, k.j, lane, k.rb_min, k.rb_idx);
+            band_argmin<W>(S.C, (k.t - c + 1 > 0) ? k.t - c + 1 : 0, k.t, lane, k.cb_min, k.cb_idx);
         }
-    } else if (wave == 0) {  // band minima are not persisted: rebuild them from the reloaded bands
-        band_argmin<W>(S.R, (j - c + 1 > 0) ? j - c + 1 : 0, j, lane, rb_min, rb_idx);
-        band_argmin<W>(S.C, (t - c + 1 > 0) ? t - c + 1 : 0, t, lane, cb_min, cb_idx);
-    }
-    if (wave == 0) {
         if (lane == 0) {
-            S.t = t;
-            S.j = j;
+            S.t = k.t;
+            S.j = k.j;
         }
     }
     __syncthreads();
     // prime the cost buffers for the first step (all threads), then publish its plan
     int buf = 0;
-    precompute(S.t, S.j, S.Dr[0], S.Dc[0], tid, NT);
-    if (wave == 0) make_plan();
+    otw_precompute<W>(S, e, S.t, S.j, S.Dr[0], S.Dc[0], tid, NT);
+    if (wave == 0) otw_make_plan<W>(S, k, e);
     __syncthreads();
 
     // ---- step loop: one iteration = one row strip and/or one column strip + one decide()
     for (;;) {
         RTS_STAMP(0);
-        const int pt = S.plan_t, j0 = S.plan_j0, pflags = S.plan_flags;
+        const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
+                  pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
         if (pflags & kPlanExit) break;
         const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
         const bool stop = (pflags & kPlanStop) != 0;
@@ -647,41 +723,15 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         const bool col_active = do_col && !stop;
         double *Dr = S.Dr[buf], *Dc = S.Dc[buf];
 
-        // -- predecessor phase: a = min over the two out-of-strip predecessors, costs are ready
-        if (do_row) {
-            for (int i = tid; i < nr; i += NT) {
-                const int k = k1r + i;
-                const double d = Dr[swz<W>(k)];
-                double av = S.R[swz<W>(k)] + d;  // (t-1, k): always present
-                if (k > 0) av = vmin(av, S.R[swz<W>(k - 1)] + 2 * d);
-                S.Ar[swz<W>(k)] = av;
-            }
-        }
-        if (col_active) {
-            for (int i = tid; i < nc; i += NT) {
-                const int k = k1c + i;
-                const double d = Dc[swz<W>(k)];
-                // (k, jn-1) is C[k]; for the corner cell of a Both step it is this step's row
-                // result, so only the diagonal term is formed here and the rest in the fix-up.
-                const bool corner = do_row && (k == pt);
-                double av = corner ? inf : S.C[swz<W>(k)] + d;
-                if (k > 0) av = vmin(av, S.C[swz<W>(k - 1)] + 2 * d);
-                S.Ac[swz<W>(k)] = av;
-            }
-        }
-        RTS_STAMP(1);
-        __syncthreads();
-        RTS_STAMP(2);
-
         // -- chain phase: row strip on wave 0, column strip on wave 1; spare waves pre-compute the
         //    next step's costs meanwhile
         const int col_wave = (NW > 1 && do_row) ? 1 : 0;
-        double row_last = 0.0, rf_min = inf;
+        double rf_min = inf;
         int rf_idx = 0x7fffffff;
         if (do_row && wave == 0) {
             const double x_in = (k1r > 0) ? sentinel : inf;  // (t, k1r-1) was never evaluated
             const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // row band's lower end at decide()
-            row_last = strip_chain<W>(Dr, S.Ar, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx);
+            strip_chain<W>(Dr, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx);
             if (lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
         }
         if (col_active && wave == col_wave) {
@@ -689,64 +739,72 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             const int ncc = nc - (do_row ? 1 : 0);            // corner cell waits for the row strip
             double fm;
             int fi;
-            const double last = strip_chain<W>(Dc, S.Ac, S.C, k1c, ncc, x_in, lane, k1c, fm, fi);
+            // the corner's diagonal term needs column jn-1 at row t-1, which the chain is about to overwrite
+            const double dcorner = Dc[swz<W>(pt)];
+            const double pa = (do_row && pt > 0) ? S.C[swz<W>(pt - 1)] + 2 * dcorner : inf;
+            strip_chain<W>(Dc, S.C, k1c, ncc, x_in, lane, k1c, fm, fi);
             if (lane == 0) {
+                S.corner_pa = pa;
+                S.corner_d = dcorner;
                 if (k1c > 0) S.C[swz<W>(k1c - 1)] = sentinel;
-                S.col_last = last;
                 S.cfresh_min = fm;
                 S.cfresh_idx = fi;
             }
         }
         RTS_STAMP(3);
-        if (!stop && wave >= HW0) precompute(pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
+        if (!stop && wave >= HW0)
+            otw_precompute<W>(S, e, pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
         RTS_STAMP(4);
         __syncthreads();
         RTS_STAMP(5);
 
         // -- corner fix-up, decide, next plan (wave 0, register state)
         if (wave == 0) {
-            if (!stop && deferred_update && pend_dir != -2) {  // livenote_v2.py:149-155
-                run_count = (pend_dir == prev) ? run_count + 1 : 1;
-                if (pend_dir != RTS_DIR_BOTH) prev = pend_dir;
-                pend_dir = -2;
+            if (!stop && e.deferred_update && k.pend_dir != -2) {  // livenote_v2.py:149-155
+                k.run_count = (k.pend_dir == k.prev) ? k.run_count + 1 : 1;
+                if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
+                k.pend_dir = -2;
             }
             if (do_row) {
-                rows += 1;
-                cells += nr;
-                consumed = pt + 1;
+                k.rows += 1;
+                k.cells += nr;
+                k.consumed = pt + 1;
             }
             double cl = 0.0, cf_min = inf;
             int cf_idx = 0x7fffffff;
+            // last cell of the row strip = acc[t][j0]; of the column chain = acc[t-1][jn] (Both) or acc[t][jn]
+            const double row_last = do_row ? rfl(S.R[swz<W>(j0)]) : 0.0;
             if (do_row && !col_active && lane == 0) S.C[swz<W>(pt)] = row_last;  // column j0 gains row t
             if (col_active) {
-                cl = S.col_last;
-                cf_min = S.cfresh_min;
-                cf_idx = S.cfresh_idx;
+                const int ncc = nc - (do_row ? 1 : 0);
+                cl = (ncc > 0) ? rfl(S.C[swz<W>(k1c + ncc - 1)]) : ((k1c > 0) ? sentinel : inf);
+                cf_min = rfl(S.cfresh_min);
+                cf_idx = __builtin_amdgcn_readfirstlane(S.cfresh_idx);
                 if (do_row) {
-                    const double d = Dc[swz<W>(pt)];
-                    const double av = vmin(row_last + d, S.Ac[swz<W>(pt)]);
+                    const double d = rfl(S.corner_d);
+                    const double av = vmin(row_last + d, rfl(S.corner_pa));
                     cl = vmin(av, cl + d);  // cl was the value of (t-1, jn), or the sentinel carry
                     if (lane == 0) S.C[swz<W>(pt)] = cl;
                 }
                 if (lane == 0) S.R[swz<W>(jn)] = cl;  // row t gains column jn
-                cols += 1;
-                cells += nc;
+                k.cols += 1;
+                k.cells += nc;
             }
             RTS_STAMP(6);
             if (stop) {
-                status = RTS_STOP_REF_END;
-                t = pt;
-                j = jn;
-                pending_col = 0;
+                k.status = RTS_STOP_REF_END;
+                k.t = pt;
+                k.j = jn;
+                k.pending_col = 0;
             } else {
                 // row band: fresh from this step's row strip, plus the corner a column strip appended;
                 // column band: fresh from this step's column strip (its corner cell is outside the
                 // chain), or the old band plus the row strip's last cell
-                decide(pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl, do_row,
-                       col_active ? cl : row_last, false);
+                otw_decide<W>(S, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl,
+                              do_row, col_active ? cl : row_last, false);
             }
             RTS_STAMP(7);
-            make_plan();
+            otw_make_plan<W>(S, k, e);
         }
         RTS_STAMP(8);
         __syncthreads();
@@ -760,7 +818,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         const int t_state = te;
         if (te > a.live_cap - 1) te = a.live_cap - 1;
         if (je > N - 1) je = N - 1;
-        double *bb = a.bands + (size_t)b * 2 * (c + 1);
+        double *bb = a.bands + (size_t)e.b * 2 * (c + 1);
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
         for (int i = tid; i <= c; i += NT) {
             const int y = je - c + i, x = te - c + i;
@@ -770,26 +828,26 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     }
 #ifdef RTS_OTW_STAMPS
     if (tid == 0 && a.debug)
-        for (int i = 0; i < 12; i++) a.debug[(size_t)b * 16 + i] = stamp_sum[i];
+        for (int i = 0; i < 12; i++) a.debug[(size_t)e.b * 16 + i] = stamp_sum[i];
 #endif
     if (tid == 0) {
-        st[RTS_ST_T] = t;
-        st[RTS_ST_J] = j;
+        st[RTS_ST_T] = k.t;
+        st[RTS_ST_J] = k.j;
         // LiveNote's set_live keeps the direction in a local; self.direction stays "both"
-        st[RTS_ST_DIRECTION] = deferred_update ? RTS_DIR_BOTH : dir;
-        st[RTS_ST_PREVIOUS] = prev;
-        st[RTS_ST_RUN_COUNT] = run_count;
-        st[RTS_ST_STATUS] = status;
-        st[RTS_ST_FIRST_INSERT] = first;
-        st[RTS_ST_N_PATH] = n_path;
-        st[RTS_ST_CONSUMED] = consumed;
-        st[RTS_ST_ROW_STRIPS] = rows;
-        st[RTS_ST_COL_STRIPS] = cols;
-        st[RTS_ST_CELLS_LO] = (int32_t)(uint32_t)(cells & 0xffffffffLL);
-        st[RTS_ST_CELLS_HI] = (int32_t)(uint32_t)((unsigned long long)cells >> 32);
-        st[RTS_ST_PATH_TRUNCATED] = truncated;
-        st[14] = pend_dir;
-        st[RTS_ST_BAND_RECOMPUTES] = recomputes;
+        st[RTS_ST_DIRECTION] = e.deferred_update ? RTS_DIR_BOTH : k.dir;
+        st[RTS_ST_PREVIOUS] = k.prev;
+        st[RTS_ST_RUN_COUNT] = k.run_count;
+        st[RTS_ST_STATUS] = k.status;
+        st[RTS_ST_FIRST_INSERT] = k.first;
+        st[RTS_ST_N_PATH] = k.n_path;
+        st[RTS_ST_CONSUMED] = k.consumed;
+        st[RTS_ST_ROW_STRIPS] = k.rows;
+        st[RTS_ST_COL_STRIPS] = k.cols;
+        st[RTS_ST_CELLS_LO] = (int32_t)(uint32_t)(k.cells & 0xffffffffLL);
+        st[RTS_ST_CELLS_HI] = (int32_t)(uint32_t)((unsigned long long)k.cells >> 32);
+        st[RTS_ST_PATH_TRUNCATED] = k.truncated;
+        st[14] = k.pend_dir;
+        st[RTS_ST_BAND_RECOMPUTES] = k.recomputes;
     }
 }
 
@@ -933,7 +991,7 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     h->cost_kind = cost_kind;
     h->W = 64;
     while (h->W < c + 12) h->W *= 2;
-    h->waves = 4;
+    h->waves = 8;  // waves 0/1 run the chains, 2..7 pre-compute the next step's costs
     h->live_cap = 2 * N;
     h->path_cap = 3 * N + 8;  // one point per decide(); decides <= row strips + column strips <= 2N + N
     hipError_t e;

@@ -46,7 +46,7 @@ def main():
         buf[b, :l.shape[1]] = torch.from_numpy(l.T.copy()).float()
     live_d = buf.to(dev)
     len_d = torch.tensor([l.shape[1] for l in lives], dtype=torch.int32, device=dev)
-    names = ["read plan", "predecessor phase", "barrier1", "chain (waves 0/1)", "precompute (helpers)", "barrier2", "fixup", "decide", "plan+refill/barrier3"]
+    names = ["barrier3+read plan", "-", "-", "chain (waves 0/1)", "precompute (helpers)", "barrier2", "fixup", "decide", "plan+refill"]
     for waves in (1, 2, 4, 8):
         h = vp()
         assert L.rts_otw_create(ref_d.data_ptr(), 0, 12, N, B, c, 3, 0, 0, ctypes.byref(h)) == 0
