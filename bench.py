@@ -38,7 +38,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="feature dtype in HBM")
     ap.add_argument("--cpu-streams", type=int, default=-1, help="streams timed on the CPU oracle (-1 = all on rank 0)")
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline / parity gate (profiling runs)")
-    ap.add_argument("--traffic-json", default="", help="file with PMC-derived HBM bytes per launch to report")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "otw_traffic.json"),
+                    help="PMC-derived HBM bytes per launch (from the committed rocprofv3 passes) to report as roofline.traffic")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +115,8 @@ def main():
         mean_launch_s = float(np.mean(launch_ms)) * 1e-3
         achieved = alg_bytes / mean_launch_s / 1e9
         traffic = None
-        if args.traffic_json and os.path.exists(args.traffic_json):
+        default_workload = (B == 64 and args.c == 500 and args.n_ref == 2200 and args.dtype == "f32")
+        if default_workload and args.traffic_json and os.path.exists(args.traffic_json):
             traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
         result = {
             "metric": "aligned chroma frames/sec, batch=64 OTW c=500; path-index match vs CPU ref",
