@@ -58,12 +58,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from real_time_audio_sync_amd import otw_batch, synth
+    from real_time_audio_sync_amd import otw_batch, shard, synth
 
     # ---- workload: one reference, `batch` different time-warped noisy renditions per rank
     B = args.batch
     ref = synth.synth_ref(args.n_ref, seed=1000)
-    lives = [synth.synth_live(ref, seed=1001 + rank * B + b) for b in range(B)]
+    lo, hi = shard.partition(B * world, world, rank)  # contiguous slice of the global stream list
+    lives = [synth.synth_live(ref, seed=shard.stream_seed(1000, g)) for g in range(lo, hi)]
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     eng = otw_batch.BatchedOTW(ref, args.c, args.max_run_count, batch=B, variant="otw", dtype=tdt, device=dev,
                                waves=(args.waves or None))
@@ -99,15 +100,8 @@ def main():
     # A = 4*cells + 48 + 48*n_col + 8*n_path bytes per live frame, summed exactly
     alg_bytes = 4 * cells + 48 * frames + 48 * n_col + 8 * n_path
 
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        ft = torch.tensor([frames], dtype=torch.int64, device=dev)
-        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
-        total_frames = int(ft.item())
-    else:
-        total_frames = frames
+    # the only collectives in the run: max clock and frame count for the report (never on the data path)
+    elapsed, total_frames = shard.reduce_clock_and_count(elapsed, frames, device=dev)
 
     result = None
     if rank == 0:

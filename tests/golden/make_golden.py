@@ -263,6 +263,41 @@ def main():
         # mono float32 sample = (L + R) / 65536 exactly (librosa.load semantics); store L + R
         aud[key + "_lr_sum"] = raw.astype(np.int32).sum(axis=1).astype(np.int32)
     np.savez_compressed(os.path.join(HERE, "chopin_20b_audio.npz"), **aud)
+
+    # ---- accuracy metric (tests.py:29-137): the reference's test_simple class, cut out of tests.py as
+    # text (the module itself runs a whole evaluation at import, tests.py:278-283), on the chopin
+    # pair's ground-truth CSVs -- which are copied here as data -- for the WTW known-answer path and
+    # the DTW golden path.
+    import json
+    src = open(os.path.join(REF, "tests.py")).read()
+    a = src.index("class test_simple():")
+    b = src.index("params = {'search_band_width': 50", a)
+    from lib2to3 import refactor
+    tool = refactor.RefactoringTool(["lib2to3.fixes.fix_print"])
+    cls_src = str(tool.refactor_string("import csv\n" + src[a:b] + "\n", "tests_class"))
+    ns = {}
+    exec(compile(cls_src, "tests.py:test_simple", "exec"), ns)
+    for fn in ("chopin_rubinstein_20b.csv", "chopin_rachmaninoff_20b.csv"):
+        shutil.copyfile(os.path.join(REF, "Songs/chopin", fn), os.path.join(HERE, fn))
+    kat = np.loadtxt(os.path.join(HERE, "wtw_test_20b.txt"), dtype=np.int64)
+    ev = {}
+    shifted = kat + np.array([[0, 25]])   # a deliberately bad alignment so the counters are exercised
+    drift = np.stack([kat[:, 0], (kat[:, 1] * 0.8).astype(np.int64)], axis=1)
+    ev_paths = {"shifted": shifted.tolist(), "drift": drift.tolist()}
+    for name, path in (("wtw_known_answer", kat), ("dtw_chopin", dt["dtw_chopin/path"]), ("shifted", shifted),
+                       ("drift", drift)):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            t = ns["test_simple"](os.path.join(REF, "Songs/chopin/chopin_rubinstein_20b.wav"),
+                                  os.path.join(REF, "Songs/chopin/chopin_rachmaninoff_20b.wav"),
+                                  [(int(l), int(r)) for l, r in path])
+            ret = t.get_error()
+        pcts = [float(line.split(":")[1].strip().rstrip("%")) for line in buf.getvalue().splitlines()
+                if line.startswith("Percent incorrect")]
+        ev[name] = dict(returned=ret, percent_lines=pcts)
+        print("%-28s get_error() -> %r  %s" % (name, ret, pcts))
+    ev["_paths"] = ev_paths
+    json.dump(ev, open(os.path.join(HERE, "eval_golden.json"), "w"))
     print("wrote fixtures to", HERE)
 
 
