@@ -41,7 +41,16 @@ def main():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "otw_traffic.json"),
                     help="PMC-derived HBM bytes per launch (from the committed rocprofv3 passes) to report as roofline.traffic")
     args = ap.parse_args()
+    verbose = bool(os.environ.get("BENCH_VERBOSE"))
 
+    def note(msg):
+        if verbose:
+            print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+    if verbose:
+        import faulthandler
+        faulthandler.dump_traceback_later(90, repeat=True, file=sys.stderr)
+    note("start rank=%s world=%s" % (os.environ.get("RANK"), os.environ.get("WORLD_SIZE")))
     import torch
     import torch.distributed as dist
 
@@ -69,6 +78,7 @@ def main():
     eng = otw_batch.BatchedOTW(ref, args.c, args.max_run_count, batch=B, variant="otw", dtype=tdt, device=dev,
                                waves=(args.waves or None))
     live_dev, len_dev = eng.pack(lives)
+    note("inputs resident")
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -88,6 +98,7 @@ def main():
         ev1[i].record()
     barrier()
     t1 = time.perf_counter()
+    note("timed region done")
     elapsed = t1 - t0
     launch_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
 
