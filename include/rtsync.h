@@ -127,6 +127,11 @@ int rts_otw_read_bands(rts_otw *h, int b, double *row_band, double *col_band, vo
 /* Device-side views for zero-copy consumers (torch): path buffer [B][path_cap][2] int32 and state
  * [B][RTS_STATE_LEN] int32. */
 int rts_otw_device_views(rts_otw *h, int32_t **path_dev, int *path_cap, int32_t **state_dev);
+/* Optional mirror of the reference's dense matrices (otw_eran.py:23,27; plotted by livenote_v2.ipynb):
+ * acc_dev / cost_dev are caller-owned double [B][2N][N] buffers that every evaluated cell is also
+ * written to (never-evaluated cells hold the sentinel 1e10 / +inf, resp. -1).  NULL, NULL switches it
+ * off.  Resets the handle (the matrices are re-initialised on every reset / run). */
+int rts_otw_set_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *stream);
 /* Tuning knob, not semantics: waves per stream workgroup (1, 2, 4 or 8).  Results are identical. */
 int rts_otw_set_waves(rts_otw *h, int waves);
 /* Average device time of the last kernel launches is measured by the caller with HIP events on

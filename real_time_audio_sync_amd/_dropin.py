@@ -18,6 +18,7 @@ class OtwDropIn(object):
     _names = _DIR_NAMES_CAP
     _msg_overflow = "Done. Ran out of room in pre-allocated live-sequence"
     _msg_stop = "Done. Ran out of ref-sequence"
+    DENSE_LIMIT_BYTES = 2 << 30  # keep acc_cost / cost (2 x 2N x N float64) only below 2 GiB
 
     def _setup(self, ref, band, max_run_count, euclid=False, device="cuda:0"):
         ref = np.asarray(ref, dtype=np.float64)
@@ -27,6 +28,10 @@ class OtwDropIn(object):
         self._eng = BatchedOTW(ref, band, max_run_count, batch=1, variant=self._variant, euclid=euclid,
                                device=device, dtype=torch.float64)
         self._dev = self._eng.device
+        # the reference's dense (2N x N) matrices: mirrored on the device when they fit comfortably
+        self._dense = 2 * (2 * ref.shape[1]) * ref.shape[1] * 8 <= self.DENSE_LIMIT_BYTES
+        if self._dense:
+            self._eng.enable_dense()
         self._frame = torch.empty((1, ref.shape[0]), dtype=torch.float64, device=self._dev)
         self._path_is_array = False
         self._reported = nat.RUNNING
@@ -89,10 +94,21 @@ class OtwDropIn(object):
         negative indices.  The dense (2N x N) matrices of the reference are never materialised."""
         return self._eng.bands(0)
 
+    def _dense_matrix(self, which):
+        if not self._dense:
+            raise NotImplementedError(
+                "the dense (2N x N) %s of the reference is not kept for a reference this long (it would need "
+                "%.1f GiB); use .bands() for the two live bands the algorithm actually reads"
+                % (which, 2 * (2 * self._ref_host.shape[1]) * self._ref_host.shape[1] * 8 / 2.0 ** 30))
+        torch.cuda.synchronize(self._dev)
+        return (self._eng.dense_acc if which == "acc_cost" else self._eng.dense_cost)[0].cpu().numpy()
+
     @property
     def acc_cost(self):
-        raise NotImplementedError(
-            "the dense (2N x N) acc_cost of the reference is not materialised; use .bands() for the "
-            "two live bands (row t / column j) the algorithm actually reads")
+        """(2N, N) float64, sentinel (1e10 / inf) where never evaluated -- otw_eran.py:27, livenote_v2.py:22-23."""
+        return self._dense_matrix("acc_cost")
 
-    cost = acc_cost
+    @property
+    def cost(self):
+        """(2N, N) float64, -1 where never evaluated -- otw_eran.py:23."""
+        return self._dense_matrix("cost")

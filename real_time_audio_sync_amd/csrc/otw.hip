@@ -50,6 +50,8 @@ struct OtwArgs {
     int ref_f64, live_f64;
     int clamp_len;            // run mode: never read past live_stride frames
     long long *debug;         // diagnostic builds only (-DRTS_OTW_STAMPS): [B][16] cycle sums
+    double *dense_acc;        // optional [B][2N][N]: the reference's dense acc_cost (otw_eran.py:27), NULL = off
+    double *dense_cost;       // optional [B][2N][N]: the reference's dense cost (otw_eran.py:23)
 };
 
 template <int W>
@@ -196,9 +198,10 @@ __device__ __forceinline__ double wave_min(double x) {
 // corner slot, which the fix-up rewrites; every band position is written with its real value
 // before it is ever read (rows/columns only grow at the top index).  Valid cells are always finite:
 // each has a computed predecessor in the previous row (row strip) or column (column strip).
-template <int W>
+template <int W, bool DENSE>
 __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, double *__restrict__ band, int k1, int n,
-                                            double x_in, int lane, int lo_arg, double &fmin_out, int &fidx_out) {
+                                            double x_in, int lane, int lo_arg, double &fmin_out, int &fidx_out,
+                                            double *dense_acc, double *dense_cost, long long dense_stride) {
     constexpr int L = W / 64;
     constexpr int LOG_L = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : 3;
     const double inf = INFINITY;
@@ -248,6 +251,16 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, doubl
     }
 #pragma unroll
     for (int m = 0; m < L; m++) band[slot[m + 1]] = v[m];
+    if (DENSE) {  // optional: mirror the strip into the reference's dense matrices (cell i at base + i*stride)
+#pragma unroll
+        for (int m = 0; m < L; m++) {
+            if (m < nloc) {
+                const long long off = (long long)(L * lane + m) * dense_stride;
+                dense_acc[off] = v[m];
+                dense_cost[off] = D[m];
+            }
+        }
+    }
     // first minimum over positions >= lo_arg: lo_arg is k1 or k1 + 1, so at most the very first
     // cell is excluded
     const double v0 = (lane == 0 && lo_arg > k1) ? inf : v[0];
@@ -547,7 +560,7 @@ __device__ __forceinline__ void otw_make_plan(OtwLds<W> &S, OtwCtl &k, const Otw
     }
 }
 
-template <int W, int NW>
+template <int W, int NW, bool DENSE>
 __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     constexpr int NT = 64 * NW;
     // Waves >= HW0 pre-compute the next step's cell costs while waves 0/1 run the chains.  With fewer
@@ -679,6 +692,10 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             if (lane == 0) {
                 S.R[swz<W>(0)] = d;
                 S.C[swz<W>(0)] = d;
+                if (DENSE) {
+                    a.dense_acc[(long long)e.b * a.live_cap * N] = d;
+                    a.dense_cost[(long long)e.b * a.live_cap * N] = d;
+                }
             }
             k.first = 0;
             k.consumed = 1;
@@ -731,7 +748,9 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         if (do_row && wave == 0) {
             const double x_in = (k1r > 0) ? sentinel : inf;  // (t, k1r-1) was never evaluated
             const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // row band's lower end at decide()
-            strip_chain<W>(Dr, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx);
+            const long long dro = ((long long)e.b * a.live_cap + pt) * N + k1r;  // cell (pt, k1r)
+            strip_chain<W, DENSE>(Dr, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx, DENSE ? a.dense_acc + dro : nullptr,
+                                  DENSE ? a.dense_cost + dro : nullptr, 1);
             if (lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
         }
         if (col_active && wave == col_wave) {
@@ -742,7 +761,9 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             // the corner's diagonal term needs column jn-1 at row t-1, which the chain is about to overwrite
             const double dcorner = Dc[swz<W>(pt)];
             const double pa = (do_row && pt > 0) ? S.C[swz<W>(pt - 1)] + 2 * dcorner : inf;
-            strip_chain<W>(Dc, S.C, k1c, ncc, x_in, lane, k1c, fm, fi);
+            const long long dco = ((long long)e.b * a.live_cap + k1c) * N + jn;  // cell (k1c, jn)
+            strip_chain<W, DENSE>(Dc, S.C, k1c, ncc, x_in, lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
+                                  DENSE ? a.dense_cost + dco : nullptr, N);
             if (lane == 0) {
                 S.corner_pa = pa;
                 S.corner_d = dcorner;
@@ -784,7 +805,14 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                     const double d = rfl(S.corner_d);
                     const double av = vmin(row_last + d, rfl(S.corner_pa));
                     cl = vmin(av, cl + d);  // cl was the value of (t-1, jn), or the sentinel carry
-                    if (lane == 0) S.C[swz<W>(pt)] = cl;
+                    if (lane == 0) {
+                        S.C[swz<W>(pt)] = cl;
+                        if (DENSE) {
+                            const long long o = ((long long)e.b * a.live_cap + pt) * N + jn;
+                            a.dense_acc[o] = cl;
+                            a.dense_cost[o] = d;
+                        }
+                    }
                 }
                 if (lane == 0) S.R[swz<W>(jn)] = cl;  // row t gains column jn
                 k.cols += 1;
@@ -865,6 +893,12 @@ __global__ void otw_reset_kernel(int32_t *state, int B, int variant) {
     st[14] = -2;
 }
 
+__global__ void otw_fill_kernel(double *p, long long n, double v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long q = i; q < n; q += stride) p[q] = v;
+}
+
 // Append one frame per (active) stream to the handle-owned history and bump its length.
 __global__ void otw_append_kernel(double *hist, int32_t *hist_len, const void *frames, int frames_f64,
                                   const uint8_t *active, int B, int cap) {
@@ -897,22 +931,29 @@ struct rts_otw {
     double *hist;       // [B][live_cap][F], allocated on first insert
     int32_t *hist_len;  // [B]
     long long *debug;   // diagnostic builds only
+    double *dense_acc, *dense_cost;  // caller-owned, optional
 };
 
 namespace rts {
 
-template <int W, int NW>
-static int launch_advance(const OtwArgs &args, int B, hipStream_t s) {
+template <int W, int NW, bool DENSE>
+static int launch_advance_d(const OtwArgs &args, int B, hipStream_t s) {
     const size_t smem = sizeof(OtwLds<W>);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
-        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&otw_advance_kernel<W, NW>),
+        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&otw_advance_kernel<W, NW, DENSE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
-    hipLaunchKernelGGL((otw_advance_kernel<W, NW>), dim3(B), dim3(64 * NW), smem, s, args);
+    hipLaunchKernelGGL((otw_advance_kernel<W, NW, DENSE>), dim3(B), dim3(64 * NW), smem, s, args);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
+}
+
+// The dense mirror is a separate instantiation so that the default kernel carries none of its code.
+template <int W, int NW>
+static int launch_advance(const OtwArgs &args, int B, hipStream_t s) {
+    return args.dense_acc ? launch_advance_d<W, NW, true>(args, B, s) : launch_advance_d<W, NW, false>(args, B, s);
 }
 
 template <int W>
@@ -952,6 +993,8 @@ static OtwArgs base_args(const rts_otw *h) {
     a.live_cap = h->live_cap;
     a.ref_f64 = h->ref_dtype == RTS_F64;
     a.debug = h->debug;
+    a.dense_acc = h->dense_acc;
+    a.dense_cost = h->dense_cost;
     return a;
 }
 
@@ -1030,7 +1073,24 @@ int rts_otw_reset(rts_otw *h, void *stream) {
     hipLaunchKernelGGL(otw_reset_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, h->state, h->B, h->variant);
     RTS_HIP(hipGetLastError());
     RTS_HIP(hipMemsetAsync(h->hist_len, 0, sizeof(int32_t) * (size_t)h->B, s));
+    if (h->dense_acc) {  // otw_eran.py:23,27 / livenote_v2.py:21-23
+        const long long n = (long long)h->B * h->live_cap * h->N;
+        const double sentinel = (h->variant == RTS_VARIANT_OTW) ? 1e10 : (double)INFINITY;
+        hipLaunchKernelGGL(otw_fill_kernel, dim3(2048), dim3(256), 0, s, h->dense_acc, n, sentinel);
+        hipLaunchKernelGGL(otw_fill_kernel, dim3(2048), dim3(256), 0, s, h->dense_cost, n, -1.0);
+        RTS_HIP(hipGetLastError());
+    }
     return RTS_OK;
+}
+
+int rts_otw_set_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *stream) {
+    using namespace rts;
+    if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if ((acc_dev == nullptr) != (cost_dev == nullptr))
+        return set_error(RTS_ERR_INVALID, "acc_dev and cost_dev must both be given or both be NULL");
+    h->dense_acc = acc_dev;
+    h->dense_cost = cost_dev;
+    return rts_otw_reset(h, stream);
 }
 
 int rts_otw_set_waves(rts_otw *h, int waves) {

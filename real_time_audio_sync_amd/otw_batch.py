@@ -132,6 +132,15 @@ class BatchedOTW:
         nat.check(nat.lib.rts_otw_read_bands(self._h, b, rb.ctypes.data, cb.ctypes.data, self._stream()))
         return rb, cb
 
+    def enable_dense(self):
+        """Allocate and attach the reference's dense (2N x N) acc_cost / cost matrices per stream
+        (float64 device tensors [B][2N][N]); every evaluated cell is mirrored into them."""
+        self.dense_acc = torch.empty((self.B, 2 * self.N, self.N), dtype=torch.float64, device=self.device)
+        self.dense_cost = torch.empty((self.B, 2 * self.N, self.N), dtype=torch.float64, device=self.device)
+        nat.check(nat.lib.rts_otw_set_dense(self._h, self.dense_acc.data_ptr(), self.dense_cost.data_ptr(),
+                                            self._stream()))
+        return self.dense_acc, self.dense_cost
+
     def set_waves(self, waves):
         nat.check(nat.lib.rts_otw_set_waves(self._h, int(waves)))
 

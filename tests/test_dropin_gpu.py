@@ -74,5 +74,52 @@ def test_livenote_and_v2(otw_golden):
         if v2.insert(lc[:, i]) == "stop":
             break
     assert np.array_equal(np.array(v2.path), g["C_livenote_v2_euclid_c50_insert/path"])
+
+
+def test_dense_matrices_hash_equal_to_reference(otw_golden):
+    """.acc_cost / .cost, the dense (2N x N) float64 matrices the reference keeps (otw_eran.py:23,27),
+    as written by the HIP kernel: sha256 of the whole matrices equals the sha256 of the matrices the
+    reference's own code produced (tests/golden/make_golden.py)."""
+    import hashlib
+    from conftest import parse_case
+    from real_time_audio_sync_amd.otw_eran import OnlineTimeWarping
+    from real_time_audio_sync_amd.livenote import LiveNote
+    from real_time_audio_sync_amd.livenote_v2 import LiveNoteV2
+    g = otw_golden
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    for cid in ("A_otw_c50_insert", "B_otw_c500_insert", "D_otw_tie_c10_insert", "F_otw_stop_c20_insert",
+                "E_livenote_overflow_c10_insert", "C_livenote_v2_euclid_c50_insert", "G_otw_c500_insert",
+                "A_livenote_v2_c10_set_live"):
+        case = parse_case([m for m in g["cases"] if str(m).split("|")[0] == cid][0])
+        ref = g[case["group"] + "/ref"].astype(np.float64)
+        live = g[case["group"] + "/live"].astype(np.float64)
+        if case["variant"] == "otw":
+            o = OnlineTimeWarping(ref, {'c': case["c"], 'max_run_count': case["mrc"]})
+        elif case["variant"] == "livenote":
+            o = LiveNote(ref, {'search_band_width': case["c"], 'max_run_count': case["mrc"]}, {})
+        else:
+            o = LiveNoteV2(ref, {'search_band_width': case["c"], 'max_run_count': case["mrc"]}, {},
+                           chroma_diff=case["euclid"])
+        if case["mode"] == "set_live":
+            o.set_live(live)
+        else:
+            lv, ln = o._eng.pack([live], dtype=torch.float64)
+            o._eng.run(lv, ln)           # same as the insert loop, one launch
+        acc, cost = o.acc_cost, o.cost
+        assert acc.shape == (2 * ref.shape[1], ref.shape[1])
+        assert sha(acc) == str(g[cid + "/acc_sha"]), cid
+        assert sha(cost) == str(g[cid + "/cost_sha"]), cid
+        assert int((cost != -1).sum()) == int(g[cid + "/cells"]), cid
+
+
+def test_dense_matrices_refused_when_huge(monkeypatch):
+    from real_time_audio_sync_amd import _dropin
+    from real_time_audio_sync_amd.otw_eran import OnlineTimeWarping
+    from real_time_audio_sync_amd import synth
+    monkeypatch.setattr(_dropin.OtwDropIn, "DENSE_LIMIT_BYTES", 1000)
+    o = OnlineTimeWarping(synth.synth_ref(64, seed=2), {'c': 10, 'max_run_count': 3})
     with pytest.raises(NotImplementedError):
-        v2.acc_cost
+        o.acc_cost
