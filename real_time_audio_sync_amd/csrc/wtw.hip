@@ -11,7 +11,11 @@
 //      cells of a diagonal are independent, so D and B are bit-identical to the serial loops,
 //   3. backtracks B and applies the hand-over rule of wtw.py:107-128 (append sub-path points with
 //      l <= dtw_hop/hop, move (live_ptr, ref_ptr) to the last appended point) on one lane.
-// The back-pointer matrix lives in LDS for W <= 128 and in an HBM workspace above that.
+// The back-pointer matrix lives in LDS for W <= 128 and in an HBM workspace above that.  Windows of
+// more than 512 frames (BASELINE configs[4]: W = 10 000) do not fit LDS at all: the same code then
+// runs with 1024 threads, reads the window's features in place from HBM/L2 and keeps norms, the
+// three diagonals and the sub-path in a per-stream HBM workspace (workgroup-scope visibility through
+// the barrier is all the single-workgroup sweep needs).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -25,6 +29,8 @@ namespace rts {
 constexpr int kWF = 12;
 constexpr int kWtwNT = 256;
 constexpr int kWtwLdsB = 128;  // largest W whose back-pointers stay in LDS
+constexpr int kWtwLdsW = 512;  // largest W whose window (features, norms, diagonals) stays in LDS
+constexpr int kWtwMaxW = 16384;
 
 struct WtwArgs {
     const double *ref;    // [M][F]
@@ -34,6 +40,8 @@ struct WtwArgs {
     int32_t *path;        // [B][path_cap][2]
     int8_t *bwork;        // [B][W][W] or NULL when W <= kWtwLdsB
     double *dlast;        // [B][W][W] last window's D (optional, NULL = not stored)
+    double *ws;           // W > kWtwLdsW: [B][5W] doubles (nx, ny, 3 diagonals) ...
+    int32_t *ws_sub;      // ... and [B][4W] ints (sub-path)
     int M, N, W, hopf, path_cap;
 };
 
@@ -58,20 +66,22 @@ __device__ __forceinline__ double wtw_dot_strided(const double *x, const double 
     return t1 + t2;
 }
 
-__global__ void __launch_bounds__(kWtwNT) wtw_advance_kernel(WtwArgs g) {
+__global__ void __launch_bounds__(1024) wtw_advance_kernel(WtwArgs g) {
     extern __shared__ __align__(16) unsigned char wtw_smem[];
     const int W = g.W;
-    double *xs = reinterpret_cast<double *>(wtw_smem);  // [W][F] live window
-    double *ys = xs + (size_t)W * kWF;                  // [W][F] ref window
-    double *nx = ys + (size_t)W * kWF;                  // [W]
-    double *ny = nx + W;                                // [W]
-    double *diag = ny + W;                              // [3][W]
-    int32_t *sub = reinterpret_cast<int32_t *>(diag + 3 * (size_t)W);  // [2W][2]
-    int8_t *bl = reinterpret_cast<int8_t *>(sub + 4 * (size_t)W);      // [W][W] when W <= kWtwLdsB
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int kWtwNT = blockDim.x;  // 256 for LDS-resident windows, 1024 for HBM-resident ones
+    const bool big = W > kWtwLdsW;
+    double *xs_l = reinterpret_cast<double *>(wtw_smem);  // [W][F] live window   (LDS-resident case)
+    double *ys_l = xs_l + (size_t)(big ? 0 : W) * kWF;    // [W][F] ref window
+    double *nx = big ? g.ws + (size_t)b * 5 * W : ys_l + (size_t)W * kWF;  // [W]
+    double *ny = nx + W;                                                   // [W]
+    double *diag = ny + W;                                                 // [3][W]
+    int32_t *sub = big ? g.ws_sub + (size_t)b * 4 * W : reinterpret_cast<int32_t *>(diag + 3 * (size_t)W);  // [2W][2]
+    int8_t *bl = reinterpret_cast<int8_t *>(sub + 4 * (size_t)W);  // [W][W] when W <= kWtwLdsB
     __shared__ int s_chroma_ptr, s_live_ptr, s_ref_ptr, s_status, s_n_path, s_n_windows, s_go;
     __shared__ long long s_cells;
 
-    const int b = blockIdx.x, tid = threadIdx.x;
     int32_t *st = g.state + (size_t)b * 8;
     const double *live = g.live + (size_t)b * g.N * kWF;
     int8_t *Bm = (W <= kWtwLdsB) ? bl : (g.bwork + (size_t)b * W * W);
@@ -110,8 +120,13 @@ __global__ void __launch_bounds__(kWtwNT) wtw_advance_kernel(WtwArgs g) {
             int m = W;
             if (rp + m > g.M) m = g.M - rp;  // numpy slice truncation of chroma_ref[:, rp:rp+W]
             if (m <= 0) break;
-            for (int idx = tid; idx < n * kWF; idx += kWtwNT) xs[idx] = live[(size_t)lp * kWF + idx];
-            for (int idx = tid; idx < m * kWF; idx += kWtwNT) ys[idx] = g.ref[(size_t)rp * kWF + idx];
+            const double *xs = live + (size_t)lp * kWF, *ys = g.ref + (size_t)rp * kWF;  // in place when big
+            if (!big) {
+                for (int idx = tid; idx < n * kWF; idx += kWtwNT) xs_l[idx] = live[(size_t)lp * kWF + idx];
+                for (int idx = tid; idx < m * kWF; idx += kWtwNT) ys_l[idx] = g.ref[(size_t)rp * kWF + idx];
+                xs = xs_l;
+                ys = ys_l;
+            }
             __syncthreads();
             for (int i = tid; i < n; i += kWtwNT) nx[i] = sqrt(wtw_dot_chain(xs + i * kWF, xs + i * kWF));
             for (int j = tid; j < m; j += kWtwNT) ny[j] = sqrt(wtw_dot_chain(ys + j * kWF, ys + j * kWF));
@@ -164,7 +179,7 @@ __global__ void __launch_bounds__(kWtwNT) wtw_advance_kernel(WtwArgs g) {
                 sub[0] = i;
                 sub[1] = j;
                 len = 1;
-                while (!(i == 0 && j == 0) && len < 2 * W) {
+                while (!(i == 0 && j == 0) && len < 2 * W) {  // B in HBM for W > 128: ~1 us per step
                     const int8_t p = Bm[(size_t)i * W + j];
                     if (p == 1)
                         j -= 1;
@@ -264,6 +279,8 @@ struct rts_wtw {
     int32_t *appended, *state, *path;
     int8_t *bwork;
     double *dlast;
+    double *ws;
+    int32_t *ws_sub;
     size_t smem;
 };
 
@@ -280,8 +297,8 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     if (win_frames < 1) return set_error(RTS_ERR_INVALID, "dtw_win_size / hop_size must be >= 1 frame");
     if (hop_frames < 1)
         return set_error(RTS_ERR_INVALID, "dtw_hop_size / hop_size must be >= 1 frame (the reference loops forever at 0)");
-    if (win_frames > 512)
-        return set_error(RTS_ERR_UNSUPPORTED, "window of %d frames exceeds the 512 the single-workgroup DP holds", win_frames);
+    if (win_frames > kWtwMaxW)
+        return set_error(RTS_ERR_UNSUPPORTED, "window of %d frames exceeds the supported %d", win_frames, kWtwMaxW);
     rts_wtw *h = (rts_wtw *)calloc(1, sizeof(rts_wtw));
     if (!h) return set_error(RTS_ERR_INVALID, "out of host memory");
     h->ref = chroma_ref_dev;
@@ -292,14 +309,18 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     h->hopf = hop_frames;
     h->path_cap = (h->N / hop_frames + 2) * (win_frames + hop_frames + 2);
     const int W = win_frames;
-    h->smem = sizeof(double) * ((size_t)2 * W * kWF + 2 * W + 3 * W) + sizeof(int32_t) * 4 * W +
-              (W <= kWtwLdsB ? (size_t)W * W : 0) + 64;
+    const bool big = W > kWtwLdsW;
+    h->smem = big ? 64
+                  : sizeof(double) * ((size_t)2 * W * kWF + 2 * W + 3 * W) + sizeof(int32_t) * 4 * W +
+                        (W <= kWtwLdsB ? (size_t)W * W : 0) + 64;
     hipError_t e;
     if ((e = hipMalloc((void **)&h->live, sizeof(double) * kWF * (size_t)h->N * B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->appended, sizeof(int32_t) * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->state, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->path, sizeof(int32_t) * 2 * (size_t)h->path_cap * B)) != hipSuccess ||
         (W > kWtwLdsB && (e = hipMalloc((void **)&h->bwork, (size_t)B * W * W)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->ws, sizeof(double) * 5 * (size_t)W * B)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->ws_sub, sizeof(int32_t) * 4 * (size_t)W * B)) != hipSuccess) ||
         (keep_last_d && (e = hipMalloc((void **)&h->dlast, sizeof(double) * (size_t)B * W * W)) != hipSuccess) ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) {
@@ -324,6 +345,8 @@ int rts_wtw_destroy(rts_wtw *h) {
     if (h->path) (void)hipFree(h->path);
     if (h->bwork) (void)hipFree(h->bwork);
     if (h->dlast) (void)hipFree(h->dlast);
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->ws_sub) (void)hipFree(h->ws_sub);
     free(h);
     return RTS_OK;
 }
@@ -363,12 +386,14 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.path = h->path;
     g.bwork = h->bwork;
     g.dlast = h->dlast;
+    g.ws = h->ws;
+    g.ws_sub = h->ws_sub;
     g.M = h->M;
     g.N = h->N;
     g.W = h->W;
     g.hopf = h->hopf;
     g.path_cap = h->path_cap;
-    hipLaunchKernelGGL(wtw_advance_kernel, dim3(h->B), dim3(kWtwNT), h->smem, s, g);
+    hipLaunchKernelGGL(wtw_advance_kernel, dim3(h->B), dim3(h->W > kWtwLdsW ? 1024 : kWtwNT), h->smem, s, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

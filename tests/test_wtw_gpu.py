@@ -87,6 +87,61 @@ def test_batched_streams_vs_oracle():
         eng.close()
 
 
+@pytest.mark.parametrize("W,hopf,n_ref", [(700, 350, 2500), (2000, 1000, 5000)])
+def test_large_windows_hbm_resident(W, hopf, n_ref):
+    """Windows beyond the 512 frames that fit LDS run from an HBM workspace; results stay bit-exact."""
+    import oracle
+    from real_time_audio_sync_amd import synth
+    from real_time_audio_sync_amd.wtw import BatchedWTW
+    dev = torch.device("cuda:0")
+    ref, lives = synth.synth_batch(n_ref, 2, seed=90 + W)
+    eng = BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev), W, hopf, 2)
+    tmax = max(l.shape[1] for l in lives)
+    cols = np.zeros((2, tmax, 12))
+    for b, l in enumerate(lives):
+        cols[b, : l.shape[1]] = l.T
+    n_new = torch.tensor([l.shape[1] for l in lives], dtype=torch.int32, device=dev)
+    eng.push(torch.from_numpy(cols).to(dev), n_new, precheck=True)
+    for b, l in enumerate(lives):
+        o = oracle.WtwOracle(ref, W, hopf)
+        for q in range(l.shape[1]):
+            if o.push_col(l[:, q]) != oracle.RUNNING:
+                break
+        st, so = eng.state(b), o.state
+        assert o.counters["windows"] >= 2
+        assert np.array_equal(eng.path(b), o.path), (W, b)
+        assert (st["live_ptr"], st["ref_ptr"], st["status"], st["windows"]) == (
+            so["live_ptr"], so["ref_ptr"], so["status"], o.counters["windows"]), (W, b)
+    eng.close()
+
+
+def test_config5_window_10000():
+    """BASELINE configs[4] shape: 30-minute reference (19 380 frames), window 10 000 frames, window hop
+    5 000 (wtw.py:242's hop = W/2), one stream.  float64 throughout (the config's fp16 band would not
+    be bit-exact); checked against the CPU oracle on the same chroma."""
+    import oracle
+    from real_time_audio_sync_amd import synth
+    from real_time_audio_sync_amd.wtw import BatchedWTW
+    dev = torch.device("cuda:0")
+    ref = synth.synth_ref(19380, seed=500)
+    live = synth.synth_live(ref, seed=501)
+    eng = BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev), 10000, 5000, 1)
+    eng.push(torch.from_numpy(np.ascontiguousarray(live.T))[None].to(dev), precheck=True)
+    st = eng.state()
+    p = eng.path()
+    assert st["windows"] >= 1 and st["cells"] == st["windows"] * 10000 * 10000
+    # size-independent properties of a WTW path: monotone steps of at most one frame inside a window
+    step = np.diff(p, axis=0)
+    assert (step >= 0).all() and (step <= 1).all()
+    o = oracle.WtwOracle(ref, 10000, 5000)
+    for q in range(live.shape[1]):
+        if o.push_col(live[:, q]) != oracle.RUNNING:
+            break
+    assert np.array_equal(p, o.path)
+    assert (st["live_ptr"], st["ref_ptr"], st["windows"]) == (o.state["live_ptr"], o.state["ref_ptr"], o.counters["windows"])
+    eng.close()
+
+
 def test_wtw_argument_errors():
     from real_time_audio_sync_amd import _native as nat
     from real_time_audio_sync_amd.wtw import BatchedWTW
@@ -94,4 +149,4 @@ def test_wtw_argument_errors():
     with pytest.raises(nat.RtsyncError):
         BatchedWTW(ref, 20, 0)      # dtw_hop_size < hop_size: the reference would loop forever
     with pytest.raises(nat.RtsyncError):
-        BatchedWTW(ref, 513, 10)    # window too large for the single-workgroup DP
+        BatchedWTW(ref, 16385, 10)  # beyond the supported window
