@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline metric): chroma, DTW and WTW kernels on synthetic input,
+device time from HIP events on the launch stream.  Prints one JSON object per line."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, reps=5, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    return float(np.median(ts))
+
+
+def main():
+    import torch
+    from real_time_audio_sync_amd import chroma, dtw, synth, wtw
+    from real_time_audio_sync_amd.otw_batch import frames_tensor
+    dev = torch.device("cuda:0")
+    out = []
+
+    # ---- chroma: 30 minutes of audio at 22 050 Hz -> 19 380 frames (configs[4]'s reference length)
+    plan = chroma.ChromaPlan(4096, 2048, 22050)
+    rs = np.random.RandomState(0)
+    wav = torch.from_numpy((rs.rand(30 * 60 * 22050) - 0.5).astype(np.float32)).to(dev)
+    m = plan.num_frames(wav.numel(), 2048)
+    t = timed(lambda: plan.frames(wav, pad_left=2048))
+    out.append(dict(kernel="chroma_frames_kernel", frames=m, seconds=t, frames_per_s=m / t,
+                    algorithmic_bytes=m * (2048 * 4 + 96), hbm_GBps=m * (2048 * 4 + 96) / t / 1e9,
+                    note="8 KB of new float32 samples + 96 B chroma per frame; fp64 FFT; filterbank (197 KB) re-read from L2 per frame"))
+    plan512 = chroma.ChromaPlan(4096, 512, 22050)
+    m5 = plan512.num_frames(wav.numel(), 2048)
+    t = timed(lambda: plan512.frames(wav, pad_left=2048))
+    out.append(dict(kernel="chroma_frames_kernel(hop=512)", frames=m5, seconds=t, frames_per_s=m5 / t))
+
+    # ---- DTW: configs[0] shapes, one pair and a batch of 256 pairs
+    for n in (322, 1289):
+        r = synth.synth_ref(n, seed=n)
+        l = synth.synth_live(r, seed=n + 1, max_frames=n)
+        a, b = frames_tensor(l, dev, torch.float32), frames_tensor(r, dev, torch.float32)
+        t = timed(lambda: dtw.dtw_batch(a, b))
+        cells = a.shape[0] * b.shape[0]
+        out.append(dict(kernel="dtw_cost+dtw_dp", M=int(a.shape[0]), N=int(b.shape[0]), pairs=1, seconds=t,
+                        cells_per_s=cells / t, algorithmic_bytes=cells * 17,
+                        note="8 B cost + 8 B acc + 1 B back-pointer per cell; one pair = one workgroup, barrier per anti-diagonal"))
+        if n == 322:
+            ab = a.unsqueeze(0).repeat(256, 1, 1).contiguous()
+            t = timed(lambda: dtw.dtw_batch(ab, b))
+            out.append(dict(kernel="dtw_cost+dtw_dp", M=int(a.shape[0]), N=int(b.shape[0]), pairs=256, seconds=t,
+                            cells_per_s=256 * cells / t, hbm_GBps=256 * cells * 17 / t / 1e9))
+
+    # ---- WTW: 64 streams, W=100/hop=50 (wtw_live.py's setting) on a 2200-frame reference
+    ref, lives = synth.synth_batch(2200, 64, seed=3)
+    refd = torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev)
+    tmax = max(l.shape[1] for l in lives)
+    cols = np.zeros((64, tmax, 12))
+    for i, l in enumerate(lives):
+        cols[i, :l.shape[1]] = l.T
+    cols_d = torch.from_numpy(cols).to(dev)
+    n_new = torch.tensor([l.shape[1] for l in lives], dtype=torch.int32, device=dev)
+    eng = wtw.BatchedWTW(refd, 100, 50, 64)
+
+    def run_wtw():
+        eng.reset()
+        eng.push(cols_d, n_new, precheck=True)
+    t = timed(run_wtw)
+    st = eng.states()
+    frames = int(st[:, 0].sum())
+    cells = int(sum((int(np.uint32(s[7])) << 32) | int(np.uint32(s[6])) for s in st))
+    out.append(dict(kernel="wtw_advance_kernel", streams=64, W=100, hop=50, frames=frames, windows=int(st[:, 5].sum()),
+                    seconds=t, frames_per_s=frames / t, cells_per_s=cells / t))
+    # one long-form stream, W = 10 000 (configs[4] shape)
+    ref5 = synth.synth_ref(19380, seed=500)
+    live5 = synth.synth_live(ref5, seed=501)
+    eng5 = wtw.BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref5.T)).to(dev), 10000, 5000, 1)
+    c5 = torch.from_numpy(np.ascontiguousarray(live5.T))[None].to(dev)
+
+    def run5():
+        eng5.reset()
+        eng5.push(c5, precheck=True)
+    t = timed(run5, reps=3, warm=1)
+    s5 = eng5.state()
+    out.append(dict(kernel="wtw_advance_kernel(HBM-resident window)", streams=1, W=10000, hop=5000, windows=s5["windows"],
+                    seconds=t, cells_per_s=s5["cells"] / t, frames_per_s=s5["chroma_ptr"] / t,
+                    algorithmic_bytes=s5["cells"] * 1,
+                    note="1 B back-pointer per cell is the only W^2 HBM stream; single workgroup, 19 999 barriers per window"))
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()
