@@ -115,6 +115,12 @@ int rts_otw_run(rts_otw *h, const void *live_dev, int live_dtype, int T_max, con
 int rts_otw_insert(rts_otw *h, const void *frames_dev, int frames_dtype, const uint8_t *active_dev,
                    void *stream);
 
+/* Several new frames per stream in one call: the loop `while len(data) >= 4096: ... ln.insert(col);
+ * data = data[2048:]` of livenote_live.py:185-208 when a microphone buffer yields more than one hop.
+ * `frames_dev`: [B][n_max][F]; `n_new_dev`: int32[B] frames to take per stream (NULL = n_max for all). */
+int rts_otw_push(rts_otw *h, const void *frames_dev, int frames_dtype, int n_max, const int32_t *n_new_dev,
+                 void *stream);
+
 /* Getters (synchronise `stream`). */
 int rts_otw_read_state(rts_otw *h, int b, int32_t *state /* RTS_STATE_LEN */, void *stream);
 int rts_otw_read_states(rts_otw *h, int32_t *states /* [B][RTS_STATE_LEN] */, void *stream);
@@ -182,6 +188,14 @@ int rts_chroma_destroy(rts_chroma *h);
 int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, long long n_samples,
                       int pad_left, int n_frames, int normalize, void *chroma_out_dev, int out_dtype,
                       double *stft_out_dev, void *stream);
+
+/* The same for B independent sample buffers in one launch (many live microphones): samples_dev is
+ * [B][sample_stride]; stream b holds n_samples_dev[b] valid samples and gets n_frames_dev[b]
+ * (<= n_frames_max) frames written to chroma_out_dev [B][n_frames_max][12]. */
+int rts_chroma_frames_batch(rts_chroma *h, const void *samples_dev, int sample_dtype, long long sample_stride,
+                            const int32_t *n_samples_dev, int pad_left, int B, int n_frames_max,
+                            const int32_t *n_frames_dev, int normalize, void *chroma_out_dev, int out_dtype,
+                            void *stream);
 
 /* create_chroma(ft) for a power spectrum that is already on the device: spec_dev [n_frames][fft_len/2+1]. */
 int rts_chroma_project(rts_chroma *h, const double *spec_dev, int n_frames, int normalize, void *chroma_out_dev,

@@ -55,6 +55,7 @@ _decl("rts_otw_destroy", _i32, [_vp])
 _decl("rts_otw_reset", _i32, [_vp, _vp])
 _decl("rts_otw_run", _i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp])
 _decl("rts_otw_insert", _i32, [_vp, _vp, _i32, _vp, _vp])
+_decl("rts_otw_push", _i32, [_vp, _vp, _i32, _i32, _vp, _vp])
 _decl("rts_otw_read_state", _i32, [_vp, _i32, _vp, _vp])
 _decl("rts_otw_read_states", _i32, [_vp, _vp, _vp])
 _decl("rts_otw_read_path", _i32, [_vp, _i32, _vp, _i32, _pi32, _vp])
@@ -72,6 +73,7 @@ _decl("rts_chroma_num_frames", _i64, [_i64, _i32, _i32, _i32])
 _decl("rts_chroma_create", _i32, [_i32, _i32, _vp, _vp, ctypes.POINTER(_vp)])
 _decl("rts_chroma_destroy", _i32, [_vp])
 _decl("rts_chroma_frames", _i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp])
+_decl("rts_chroma_frames_batch", _i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp])
 _decl("rts_chroma_project", _i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp])
 _decl("rts_chroma_diff", _i32, [_vp, _i32, _i32, _vp, _vp])
 

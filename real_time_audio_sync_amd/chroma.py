@@ -63,6 +63,21 @@ class ChromaPlan(object):
                 self._stream()))
         return chroma, (torch.view_as_complex(stft) if want_stft else None)
 
+    def frames_batch(self, samples_dev, n_samples_dev, n_frames_dev, n_frames_max, pad_left=0, normalize=True,
+                     out_dtype=torch.float64):
+        """B sample buffers at once: samples_dev [B][stride] float32/64, n_samples_dev / n_frames_dev int32 [B].
+        Returns chroma [B][n_frames_max][12] (rows beyond n_frames_dev[b] are left untouched)."""
+        assert samples_dev.dim() == 2 and samples_dev.is_contiguous()
+        B, stride = samples_dev.shape
+        out = torch.zeros((B, int(n_frames_max), 12), dtype=out_dtype, device=self.device)
+        if n_frames_max > 0:
+            nat.check(nat.lib.rts_chroma_frames_batch(
+                self._h, samples_dev.data_ptr(), nat.F64 if samples_dev.dtype == torch.float64 else nat.F32, stride,
+                n_samples_dev.data_ptr(), int(pad_left), B, int(n_frames_max), n_frames_dev.data_ptr(),
+                int(bool(normalize)), out.data_ptr(), nat.F64 if out_dtype == torch.float64 else nat.F32,
+                self._stream()))
+        return out
+
     def project(self, spec_dev, normalize=True, out_dtype=torch.float64):
         """spec_dev: [M][n_bins] float64 power spectrum on the device -> chroma [M][12]."""
         assert spec_dev.dtype == torch.float64 and spec_dev.is_contiguous() and spec_dev.shape[1] == self.n_bins

@@ -45,6 +45,11 @@ struct ChromaArgs {
     long long n_samples;
     long long frame_offset;  // sample index of frame 0, element 0 (= -pad_left)
     int L, logL2, hop, n_frames, normalize, samples_f64, out_f64;
+    // batched form (blockIdx.y = stream): per-stream sample counts / frame counts, strides in elements
+    const int32_t *n_samples_b;  // [B] or NULL
+    const int32_t *n_frames_b;   // [B] or NULL
+    long long sample_stride;     // samples between consecutive streams
+    int out_frames_stride;       // frames between consecutive streams in chroma_out
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
@@ -105,6 +110,19 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
 
     for (int n = tid; n < N2; n += kChromaNT) tw[n] = g.twiddle[n];
     __syncthreads();
+
+    // batched launch: this workgroup's stream
+    const int sb = blockIdx.y;
+    if (g.n_frames_b) {
+        g.n_frames = g.n_frames_b[sb];
+        g.n_samples = g.n_samples_b[sb];
+        const long long so = (long long)sb * g.sample_stride;
+        g.samples = g.samples_f64 ? (const void *)(reinterpret_cast<const double *>(g.samples) + so)
+                                  : (const void *)(reinterpret_cast<const float *>(g.samples) + so);
+        const long long oo = (long long)sb * g.out_frames_stride * kCh;
+        g.chroma_out = g.out_f64 ? (void *)(reinterpret_cast<double *>(g.chroma_out) + oo)
+                                 : (void *)(reinterpret_cast<float *>(g.chroma_out) + oo);
+    }
 
     for (int frame = blockIdx.x; frame < g.n_frames; frame += gridDim.x) {
         // 1. load + window, packed as complex
@@ -311,6 +329,41 @@ int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, 
     g.out_f64 = out_dtype == RTS_F64;
     const int grid = n_frames < 512 ? n_frames : 512;
     hipLaunchKernelGGL(chroma_frames_kernel, dim3(grid), dim3(kChromaNT), h->smem_frames, (hipStream_t)stream, g);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
+int rts_chroma_frames_batch(rts_chroma *h, const void *samples_dev, int sample_dtype, long long sample_stride,
+                            const int32_t *n_samples_dev, int pad_left, int B, int n_frames_max,
+                            const int32_t *n_frames_dev, int normalize, void *chroma_out_dev, int out_dtype,
+                            void *stream) {
+    using namespace rts;
+    if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (!samples_dev || !n_samples_dev || !n_frames_dev || !chroma_out_dev)
+        return set_error(RTS_ERR_INVALID, "NULL device buffer");
+    if ((sample_dtype != RTS_F32 && sample_dtype != RTS_F64) || (out_dtype != RTS_F32 && out_dtype != RTS_F64))
+        return set_error(RTS_ERR_INVALID, "bad dtype");
+    if (B < 1 || n_frames_max < 0 || pad_left < 0 || sample_stride < 0) return set_error(RTS_ERR_INVALID, "bad size");
+    if (n_frames_max == 0) return RTS_OK;
+    ChromaArgs g;
+    memset(&g, 0, sizeof(g));
+    g.samples = samples_dev;
+    g.window = h->window;
+    g.twiddle = h->twiddle;
+    g.fb = h->fb;
+    g.chroma_out = chroma_out_dev;
+    g.frame_offset = -(long long)pad_left;
+    g.L = h->L;
+    g.hop = h->hop;
+    g.normalize = normalize;
+    g.samples_f64 = sample_dtype == RTS_F64;
+    g.out_f64 = out_dtype == RTS_F64;
+    g.n_samples_b = n_samples_dev;
+    g.n_frames_b = n_frames_dev;
+    g.sample_stride = sample_stride;
+    g.out_frames_stride = n_frames_max;
+    const int gx = n_frames_max < 64 ? n_frames_max : 64;
+    hipLaunchKernelGGL(chroma_frames_kernel, dim3(gx, B), dim3(kChromaNT), h->smem_frames, (hipStream_t)stream, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

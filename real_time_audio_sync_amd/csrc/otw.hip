@@ -916,6 +916,27 @@ __global__ void otw_append_kernel(double *hist, int32_t *hist_len, const void *f
     if (f == 0) hist_len[b] = n + 1;  // may exceed cap: the kernel reports LIVE_OVERFLOW at t >= 2N
 }
 
+// Append n_new[b] (or n_uniform) frames from frames [B][n_max][F] to the history of stream b.
+__global__ void otw_append_many_kernel(double *hist, int32_t *hist_len, const void *frames, int frames_f64,
+                                       const int32_t *n_new, int n_uniform, int n_max, int B, int cap) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int nn = n_new ? n_new[b] : n_uniform;
+    const int base = hist_len[b];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nn * kF; idx += blockDim.x) {
+        const int fr = base + idx / kF;
+        if (fr < cap) {
+            const size_t src = (size_t)b * n_max * kF + idx;
+            hist[((size_t)b * cap + fr) * kF + idx % kF] =
+                frames_f64 ? reinterpret_cast<const double *>(frames)[src]
+                           : (double)reinterpret_cast<const float *>(frames)[src];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) hist_len[b] = base + (nn > 0 ? nn : 0);
+}
+
 }  // namespace rts
 
 // ------------------------------------------------------------------------------------------------
@@ -1136,6 +1157,30 @@ int rts_otw_insert(rts_otw *h, const void *frames_dev, int frames_dtype, const u
     }
     hipLaunchKernelGGL(otw_append_kernel, dim3(h->B), dim3(64), 0, s, h->hist, h->hist_len, frames_dev,
                        frames_dtype == RTS_F64, active_dev, h->B, h->live_cap);
+    RTS_HIP(hipGetLastError());
+    OtwArgs a = base_args(h);
+    a.live = h->hist;
+    a.live_len = h->hist_len;
+    a.live_stride = h->live_cap;
+    a.live_f64 = 1;
+    a.mode = RTS_MODE_INSERT_LOOP;
+    return launch(h, a, s);
+}
+
+int rts_otw_push(rts_otw *h, const void *frames_dev, int frames_dtype, int n_max, const int32_t *n_new_dev,
+                 void *stream) {
+    using namespace rts;
+    if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (n_max < 0) return set_error(RTS_ERR_INVALID, "n_max < 0");
+    if (n_max == 0) return RTS_OK;
+    if (!frames_dev) return set_error(RTS_ERR_INVALID, "frames_dev is NULL");
+    if (frames_dtype != RTS_F32 && frames_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad frames_dtype %d", frames_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->hist) {
+        RTS_HIP(hipMalloc((void **)&h->hist, sizeof(double) * kF * (size_t)h->live_cap * h->B));
+    }
+    hipLaunchKernelGGL(otw_append_many_kernel, dim3(h->B), dim3(128), 0, s, h->hist, h->hist_len, frames_dev,
+                       frames_dtype == RTS_F64, n_new_dev, n_max, n_max, h->B, h->live_cap);
     RTS_HIP(hipGetLastError());
     OtwArgs a = base_args(h);
     a.live = h->hist;

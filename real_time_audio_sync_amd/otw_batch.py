@@ -95,6 +95,13 @@ class BatchedOTW:
                                          active_dev.data_ptr() if active_dev is not None else None,
                                          self._stream()))
 
+    def push(self, frames_dev, n_new_dev=None):
+        """Several frames per stream: frames_dev [B][n_max][12]; n_new_dev optional int32 [B]."""
+        assert frames_dev.is_contiguous() and frames_dev.shape[0] == self.B and frames_dev.shape[2] == 12
+        nat.check(nat.lib.rts_otw_push(self._h, frames_dev.data_ptr(), _np_dtype_code(frames_dev.dtype),
+                                       int(frames_dev.shape[1]), n_new_dev.data_ptr() if n_new_dev is not None else None,
+                                       self._stream()))
+
     def reset(self):
         nat.check(nat.lib.rts_otw_reset(self._h, self._stream()))
 
