@@ -432,37 +432,34 @@ __device__ __forceinline__ void otw_decide(OtwLds<W> &S, OtwCtl &k, const OtwEnv
     const int c = e.c;
     const int j1 = (jj - c + 1 > 0) ? jj - c + 1 : 0;
     const int t1 = (tt - c + 1 > 0) ? tt - c + 1 : 0;
-    double rmin, cmin;
-    int ridx, cidx;
-    if (full) {
-        band_argmin<W>(S.R, j1, jj, e.lane, rmin, ridx);
-        band_argmin<W>(S.C, t1, tt, e.lane, cmin, cidx);
-    } else {
-        if (row_fresh) {
-            rmin = rf_min;
-            ridx = rf_idx;
-        } else {
-            rmin = k.rb_min;
-            ridx = k.rb_idx;
-            if (ridx < j1) {  // the old minimum slid out of the window
-                band_argmin<W>(S.R, j1, row_corner ? jj - 1 : jj, e.lane, rmin, ridx);
-                k.recomputes += 1;
+    double rmin = row_fresh ? rf_min : k.rb_min, cmin = col_fresh ? cf_min : k.cb_min;
+    int ridx = row_fresh ? rf_idx : k.rb_idx, cidx = col_fresh ? cf_idx : k.cb_idx;
+    // full recomputation: always for `full`, otherwise only when a kept minimum slid out of its window
+    const bool need_r = full || (!row_fresh && ridx < j1);
+    const bool need_c = full || (!col_fresh && cidx < t1);
+    if (need_r || need_c) {
+        for (int which = 0; which < 2; which++) {  // a single inlined instance of the wave reduction
+            if (!(which ? need_c : need_r)) continue;
+            const double *band = which ? S.C : S.R;
+            const int lo = which ? t1 : j1;
+            const int hi = which ? ((col_corner && !full) ? tt - 1 : tt) : ((row_corner && !full) ? jj - 1 : jj);
+            double vm;
+            int im;
+            band_argmin<W>(band, lo, hi, e.lane, vm, im);
+            if (which) {
+                cmin = vm;
+                cidx = im;
+            } else {
+                rmin = vm;
+                ridx = im;
             }
+            if (!full) k.recomputes += 1;
         }
+    }
+    if (!full) {
         if (row_corner && rc < rmin) {
             rmin = rc;
             ridx = jj;
-        }
-        if (col_fresh) {
-            cmin = cf_min;
-            cidx = cf_idx;
-        } else {
-            cmin = k.cb_min;
-            cidx = k.cb_idx;
-            if (cidx < t1) {
-                band_argmin<W>(S.C, t1, col_corner ? tt - 1 : tt, e.lane, cmin, cidx);
-                k.recomputes += 1;
-            }
         }
         if (col_corner && cc < cmin) {
             cmin = cc;
@@ -711,8 +708,19 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             if (a.mode == RTS_MODE_SET_LIVE)
                 otw_decide<W>(S, k, e, 0, 0, false, 0.0, 0, false, 0.0, 0, false, 0.0, false, 0.0, true);
         } else {  // band minima are not persisted: rebuild them from the reloaded bands
-            band_argmin<W>(S.R, (k.j - c + 1 > 0) ? k.j - c + 1 : 0, k.j, lane, k.rb_min, k.rb_idx);
-            band_argmin<W>(S.C, (k.t - c + 1 > 0) ? k.t - c + 1 : 0, k.t, lane, k.cb_min, k.cb_idx);
+            for (int which = 0; which < 2; which++) {
+                const int hi = which ? k.t : k.j;
+                double vm;
+                int im;
+                band_argmin<W>(which ? S.C : S.R, (hi - c + 1 > 0) ? hi - c + 1 : 0, hi, lane, vm, im);
+                if (which) {
+                    k.cb_min = vm;
+                    k.cb_idx = im;
+                } else {
+                    k.rb_min = vm;
+                    k.rb_idx = im;
+                }
+            }
         }
         if (lane == 0) {
             S.t = k.t;
