@@ -56,56 +56,85 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// Steps 4-5 for one frame whose power spectrum sits in LDS.  `red` = LDS scratch [12][4] doubles.
-__device__ __forceinline__ void project_normalize(const ChromaArgs &g, const double *spec, double *red, int frame,
-                                                  int tid) {
+constexpr int kChromaFR = 4;  // frames sharing one pass over the filterbank
+
+// Steps 4-5 for NF <= kChromaFR frames whose power spectra sit in LDS (spec + f*spec_stride).
+// Each thread owns bins k = tid (mod 256) and keeps 12 running sums per frame, so the 197 KB
+// filterbank is read from L2 once per NF frames.  The 12 x 256 partial sums of a frame are then
+// reduced through LDS (`red`: [12][256] doubles): 192 threads add 16 each, 12 threads add the 16
+// partials in index order -- a fixed summation order, independent of NF.
+__device__ __forceinline__ void project_normalize(const ChromaArgs &g, const double *spec, int spec_stride,
+                                                  double *red, int frame0, int nf, int tid) {
     const int nb = g.L / 2 + 1;
-    double acc[kCh];
+    double acc[kChromaFR][kCh];
 #pragma unroll
-    for (int p = 0; p < kCh; p++) acc[p] = 0.0;
+    for (int f = 0; f < kChromaFR; f++)
+#pragma unroll
+        for (int p = 0; p < kCh; p++) acc[f][p] = 0.0;
     for (int k = tid; k < nb; k += kChromaNT) {
-        const double s = spec[k];
+        double w[kCh];
 #pragma unroll
-        for (int p = 0; p < kCh; p++) acc[p] = fma(g.fb[(size_t)p * nb + k], s, acc[p]);
-    }
+        for (int p = 0; p < kCh; p++) w[p] = g.fb[(size_t)p * nb + k];
 #pragma unroll
-    for (int p = 0; p < kCh; p++) {
-        double v = acc[p];
+        for (int f = 0; f < kChromaFR; f++) {
+            if (f < nf) {
+                const double sv = spec[(size_t)f * spec_stride + k];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if ((tid & 63) == 0) red[p * 4 + (tid >> 6)] = v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double c[kCh];
-        double ss = 0.0;
-#pragma unroll
-        for (int p = 0; p < kCh; p++) {
-            c[p] = ((red[p * 4 + 0] + red[p * 4 + 1]) + (red[p * 4 + 2] + red[p * 4 + 3]));
-            const double sq = c[p] * c[p];
-            ss = ss + sq;
-        }
-        double len = sqrt(ss);
-        if (!g.normalize || len < 2.2250738585072014e-308) len = 1.0;  // librosa.util.normalize, fill=None
-#pragma unroll
-        for (int p = 0; p < kCh; p++) {
-            const double v = c[p] / len;
-            if (g.out_f64)
-                reinterpret_cast<double *>(g.chroma_out)[(size_t)frame * kCh + p] = v;
-            else
-                reinterpret_cast<float *>(g.chroma_out)[(size_t)frame * kCh + p] = (float)v;
+                for (int p = 0; p < kCh; p++) acc[f][p] = fma(w[p], sv, acc[f][p]);
+            }
         }
     }
-    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < kChromaFR; f++) {
+        if (f >= nf) break;  // uniform
+#pragma unroll
+        for (int p = 0; p < kCh; p++) red[p * kChromaNT + tid] = acc[f][p];
+        __syncthreads();
+        if (tid < kCh * 16) {
+            const int p = tid >> 4, q = tid & 15;
+            double sum = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) sum = sum + red[p * kChromaNT + q * 16 + i];
+            red[kCh * kChromaNT + tid] = sum;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double c[kCh];
+            double ss = 0.0;
+#pragma unroll
+            for (int p = 0; p < kCh; p++) {
+                double sum = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) sum = sum + red[kCh * kChromaNT + p * 16 + q];
+                c[p] = sum;
+                const double sq = c[p] * c[p];
+                ss = ss + sq;
+            }
+            double len = sqrt(ss);
+            if (!g.normalize || len < 2.2250738585072014e-308) len = 1.0;  // librosa.util.normalize, fill=None
+#pragma unroll
+            for (int p = 0; p < kCh; p++) {
+                const double v = c[p] / len;
+                if (g.out_f64)
+                    reinterpret_cast<double *>(g.chroma_out)[(size_t)(frame0 + f) * kCh + p] = v;
+                else
+                    reinterpret_cast<float *>(g.chroma_out)[(size_t)(frame0 + f) * kCh + p] = (float)v;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) {
     extern __shared__ __align__(16) unsigned char ch_smem[];
     const int L = g.L, N2 = L / 2;
-    double2 *z = reinterpret_cast<double2 *>(ch_smem);  // [N2]
-    double2 *tw = z + N2;                               // [N2]
-    double *spec = reinterpret_cast<double *>(tw + N2); // [N2 + 1]
-    double *red = spec + (N2 + 2);                      // [48]
+    const int sstride = N2 + 2;                          // doubles per power spectrum in LDS
+    double2 *z = reinterpret_cast<double2 *>(ch_smem);   // [N2]   FFT work buffer; reused as reduction scratch
+    double2 *tw = z + N2;                                // [N2]
+    double *spec = reinterpret_cast<double *>(tw + N2);  // [kChromaFR][sstride]
+    // reduction scratch [12][256] + [192] doubles: the FFT buffer when it is large enough (it is free by
+    // then), a region of its own for short transforms
+    double *red = (2 * N2 >= 3264) ? reinterpret_cast<double *>(z) : spec + (size_t)kChromaFR * sstride;
     const int tid = threadIdx.x;
 
     for (int n = tid; n < N2; n += kChromaNT) tw[n] = g.twiddle[n];
@@ -124,83 +153,90 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
                                  : (void *)(reinterpret_cast<float *>(g.chroma_out) + oo);
     }
 
-    for (int frame = blockIdx.x; frame < g.n_frames; frame += gridDim.x) {
-        // 1. load + window, packed as complex
-        const long long s0 = g.frame_offset + (long long)frame * g.hop;
-        for (int n = tid; n < N2; n += kChromaNT) {
-            const long long s = s0 + 2 * n;
-            double x0 = 0.0, x1 = 0.0;
-            if (s >= 0 && s < g.n_samples)
-                x0 = g.samples_f64 ? reinterpret_cast<const double *>(g.samples)[s]
-                                   : (double)reinterpret_cast<const float *>(g.samples)[s];
-            if (s + 1 >= 0 && s + 1 < g.n_samples)
-                x1 = g.samples_f64 ? reinterpret_cast<const double *>(g.samples)[s + 1]
-                                   : (double)reinterpret_cast<const float *>(g.samples)[s + 1];
-            z[n] = make_double2(x0 * g.window[2 * n], x1 * g.window[2 * n + 1]);
-        }
-        __syncthreads();
-        // 2. Stockham radix-2, N2 points, in place via registers (read all, barrier, write all)
-        const int half = N2 / 2;
-        constexpr int kMaxBf = 4;  // butterflies per thread per stage (N2/2/256 <= 4 for L <= 4096)
-        for (int p = 1; p < N2; p <<= 1) {
-            double2 o0[kMaxBf], o1[kMaxBf];
-            int jj[kMaxBf];
-            const int tstride = N2 / p;  // twiddle index step: exp(-2 pi i k / (2p)) = tw[k * (L/2) / p ... ]
-#pragma unroll
-            for (int r = 0; r < kMaxBf; r++) {
-                const int i = tid + r * kChromaNT;
-                if (i < half) {
-                    const int k = i & (p - 1);
-                    const double2 u0 = z[i];
-                    const double2 u1 = cmul(tw[k * tstride], z[i + half]);
-                    o0[r] = make_double2(u0.x + u1.x, u0.y + u1.y);
-                    o1[r] = make_double2(u0.x - u1.x, u0.y - u1.y);
-                    jj[r] = ((i - k) << 1) + k;
-                }
+    for (int frame0 = blockIdx.x * kChromaFR; frame0 < g.n_frames; frame0 += gridDim.x * kChromaFR) {
+        const int nf = (g.n_frames - frame0 < kChromaFR) ? g.n_frames - frame0 : kChromaFR;
+        for (int f = 0; f < nf; f++) {
+            const int frame = frame0 + f;
+            // 1. load + window, packed as complex
+            const long long s0 = g.frame_offset + (long long)frame * g.hop;
+            for (int n = tid; n < N2; n += kChromaNT) {
+                const long long s = s0 + 2 * n;
+                double x0 = 0.0, x1 = 0.0;
+                if (s >= 0 && s < g.n_samples)
+                    x0 = g.samples_f64 ? reinterpret_cast<const double *>(g.samples)[s]
+                                       : (double)reinterpret_cast<const float *>(g.samples)[s];
+                if (s + 1 >= 0 && s + 1 < g.n_samples)
+                    x1 = g.samples_f64 ? reinterpret_cast<const double *>(g.samples)[s + 1]
+                                       : (double)reinterpret_cast<const float *>(g.samples)[s + 1];
+                z[n] = make_double2(x0 * g.window[2 * n], x1 * g.window[2 * n + 1]);
             }
             __syncthreads();
+            // 2. Stockham radix-2, N2 points, in place via registers (read all, barrier, write all)
+            const int half = N2 / 2;
+            constexpr int kMaxBf = 4;  // butterflies per thread per stage (N2/2/256 <= 4 for L <= 4096)
+            for (int p = 1; p < N2; p <<= 1) {
+                double2 o0[kMaxBf], o1[kMaxBf];
+                int jj[kMaxBf];
+                const int tstride = N2 / p;  // exp(-2 pi i k / (2p)) = tw[k * N2 / p]
 #pragma unroll
-            for (int r = 0; r < kMaxBf; r++) {
-                const int i = tid + r * kChromaNT;
-                if (i < half) {
-                    z[jj[r]] = o0[r];
-                    z[jj[r] + p] = o1[r];
+                for (int r = 0; r < kMaxBf; r++) {
+                    const int i = tid + r * kChromaNT;
+                    if (i < half) {
+                        const int k = i & (p - 1);
+                        const double2 u0 = z[i];
+                        const double2 u1 = cmul(tw[k * tstride], z[i + half]);
+                        o0[r] = make_double2(u0.x + u1.x, u0.y + u1.y);
+                        o1[r] = make_double2(u0.x - u1.x, u0.y - u1.y);
+                        jj[r] = ((i - k) << 1) + k;
+                    }
                 }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kMaxBf; r++) {
+                    const int i = tid + r * kChromaNT;
+                    if (i < half) {
+                        z[jj[r]] = o0[r];
+                        z[jj[r] + p] = o1[r];
+                    }
+                }
+                __syncthreads();
+            }
+            // 3. untangle: X[k] = E[k] + W_L^k O[k], E = (Z[k] + conj Z[N2-k]) / 2, O = (Z[k] - conj Z[N2-k]) / (2i)
+            const int nb = N2 + 1;
+            double *sp = spec + (size_t)f * sstride;
+            for (int k = tid; k < nb; k += kChromaNT) {
+                const double2 a = z[k & (N2 - 1)];          // Z[N2] == Z[0]
+                const double2 bq = z[(N2 - k) & (N2 - 1)];
+                const double2 b = make_double2(bq.x, -bq.y);  // conj
+                const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+                const double2 dm = make_double2(a.x - b.x, a.y - b.y);
+                const double2 o = make_double2(0.5 * dm.y, -0.5 * dm.x);  // dm / (2i)
+                const double2 w = (k < N2) ? tw[k] : make_double2(-1.0, 0.0);
+                const double2 wo = cmul(w, o);
+                const double2 x = make_double2(e.x + wo.x, e.y + wo.y);
+                if (g.stft_out) g.stft_out[(size_t)frame * nb + k] = x;
+                sp[k] = x.x * x.x + x.y * x.y;
             }
             __syncthreads();
         }
-        // 3. untangle: X[k] = E[k] + W_L^k O[k], E = (Z[k] + conj Z[N2-k]) / 2, O = (Z[k] - conj Z[N2-k]) / (2i)
-        const int nb = N2 + 1;
-        for (int k = tid; k < nb; k += kChromaNT) {
-            const double2 a = z[k & (N2 - 1)];          // Z[N2] == Z[0]
-            const double2 bq = z[(N2 - k) & (N2 - 1)];
-            const double2 b = make_double2(bq.x, -bq.y);  // conj
-            const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
-            const double2 dm = make_double2(a.x - b.x, a.y - b.y);
-            const double2 o = make_double2(0.5 * dm.y, -0.5 * dm.x);  // dm / (2i)
-            const double2 w = (k < N2) ? tw[k] : make_double2(-1.0, 0.0);
-            const double2 wo = cmul(w, o);
-            const double2 x = make_double2(e.x + wo.x, e.y + wo.y);
-            if (g.stft_out) g.stft_out[(size_t)frame * nb + k] = x;
-            spec[k] = x.x * x.x + x.y * x.y;
-        }
-        __syncthreads();
-        // 4-5
-        if (g.chroma_out) project_normalize(g, spec, red, frame, tid);
-        else __syncthreads();
+        // 4-5 for the whole group (z is free now and serves as reduction scratch)
+        if (g.chroma_out) project_normalize(g, spec, sstride, red, frame0, nf, tid);
     }
 }
 
 __global__ void __launch_bounds__(kChromaNT) chroma_project_kernel(ChromaArgs g) {
     extern __shared__ __align__(16) unsigned char ch_smem[];
     const int nb = g.L / 2 + 1;
-    double *spec = reinterpret_cast<double *>(ch_smem);
-    double *red = spec + (nb + 1);
+    const int sstride = nb + 1;
+    double *spec = reinterpret_cast<double *>(ch_smem);   // [kChromaFR][sstride]
+    double *red = spec + (size_t)kChromaFR * sstride;      // [12][256] + [192]
     const int tid = threadIdx.x;
-    for (int frame = blockIdx.x; frame < g.n_frames; frame += gridDim.x) {
-        for (int k = tid; k < nb; k += kChromaNT) spec[k] = g.spec_in[(size_t)frame * nb + k];
+    for (int frame0 = blockIdx.x * kChromaFR; frame0 < g.n_frames; frame0 += gridDim.x * kChromaFR) {
+        const int nf = (g.n_frames - frame0 < kChromaFR) ? g.n_frames - frame0 : kChromaFR;
+        for (int f = 0; f < nf; f++)
+            for (int k = tid; k < nb; k += kChromaNT) spec[(size_t)f * sstride + k] = g.spec_in[(size_t)(frame0 + f) * nb + k];
         __syncthreads();
-        project_normalize(g, spec, red, frame, tid);
+        project_normalize(g, spec, sstride, red, frame0, nf, tid);
     }
 }
 
@@ -276,8 +312,9 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
     }
     free(win);
     free(tw);
-    h->smem_frames = sizeof(double2) * 2 * N2 + sizeof(double) * (N2 + 2 + 48);
-    h->smem_project = sizeof(double) * (nb + 1 + 48);
+    h->smem_frames = sizeof(double2) * 2 * N2 + sizeof(double) * (size_t)kChromaFR * (N2 + 2) +
+                     ((2 * N2 >= 3264) ? 0 : sizeof(double) * 3264) + 64;
+    h->smem_project = sizeof(double) * ((size_t)kChromaFR * (nb + 1) + 3264) + 64;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
@@ -327,7 +364,8 @@ int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, 
     g.normalize = normalize;
     g.samples_f64 = sample_dtype == RTS_F64;
     g.out_f64 = out_dtype == RTS_F64;
-    const int grid = n_frames < 512 ? n_frames : 512;
+    const int groups = (n_frames + kChromaFR - 1) / kChromaFR;
+    const int grid = groups < 1024 ? groups : 1024;
     hipLaunchKernelGGL(chroma_frames_kernel, dim3(grid), dim3(kChromaNT), h->smem_frames, (hipStream_t)stream, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
@@ -362,7 +400,8 @@ int rts_chroma_frames_batch(rts_chroma *h, const void *samples_dev, int sample_d
     g.n_frames_b = n_frames_dev;
     g.sample_stride = sample_stride;
     g.out_frames_stride = n_frames_max;
-    const int gx = n_frames_max < 64 ? n_frames_max : 64;
+    const int groups_b = (n_frames_max + kChromaFR - 1) / kChromaFR;
+    const int gx = groups_b < 64 ? groups_b : 64;
     hipLaunchKernelGGL(chroma_frames_kernel, dim3(gx, B), dim3(kChromaNT), h->smem_frames, (hipStream_t)stream, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
@@ -385,7 +424,8 @@ int rts_chroma_project(rts_chroma *h, const double *spec_dev, int n_frames, int 
     g.n_frames = n_frames;
     g.normalize = normalize;
     g.out_f64 = out_dtype == RTS_F64;
-    const int grid = n_frames < 1024 ? n_frames : 1024;
+    const int groups_p = (n_frames + kChromaFR - 1) / kChromaFR;
+    const int grid = groups_p < 1024 ? groups_p : 1024;
     hipLaunchKernelGGL(chroma_project_kernel, dim3(grid), dim3(kChromaNT), h->smem_project, (hipStream_t)stream, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
