@@ -61,11 +61,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal switches for a one-GPU box (never set by the driver): all ranks on device 0 and the two
+    # tiny report reductions over gloo, since RCCL refuses two ranks on one device.
+    single_device = bool(os.environ.get("BENCH_SINGLE_DEVICE"))
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = 0 if single_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from real_time_audio_sync_amd import otw_batch, shard, synth
 
@@ -112,7 +120,7 @@ def main():
     alg_bytes = 4 * cells + 48 * frames + 48 * n_col + 8 * n_path
 
     # the only collectives in the run: max clock and frame count for the report (never on the data path)
-    elapsed, total_frames = shard.reduce_clock_and_count(elapsed, frames, device=dev)
+    elapsed, total_frames = shard.reduce_clock_and_count(elapsed, frames, device=dev if backend == "nccl" else None)
 
     result = None
     if rank == 0:
