@@ -196,3 +196,66 @@ def test_argument_errors(gpu):
         ob.BatchedOTW(ref, 0, 3)
     with pytest.raises(nat.RtsyncError):
         ob.BatchedOTW(ref[:11], 10, 3)  # not 12 chroma bins
+
+
+def test_randomized_small_configs(gpu):
+    """Seeded sweep over the corners the fixed cases do not reach: band widths down to c=1, references
+    and live sequences of a few frames, every variant / cost / mode / wave count, exact ties.  Each
+    configuration must match the dense CPU oracle bit for bit."""
+    ob, synth, oracle = gpu["ob"], gpu["synth"], gpu["oracle"]
+    rs = np.random.RandomState(20261004)
+    vmap = {"otw": oracle.OTW, "livenote": oracle.LIVENOTE, "livenote_v2": oracle.LIVENOTE_V2}
+    checked = 0
+    for trial in range(90):
+        n_ref = int(rs.choice([1, 2, 3, 5, 9, 17, 40, 90, 160]))
+        c = int(rs.choice([1, 2, 3, 4, 7, 8, 9, 15, 16, 17, 31, 33, 52, 63, 64, 65, 120]))
+        mrc = int(rs.choice([1, 2, 3, 5]))
+        variant = str(rs.choice(["otw", "livenote", "livenote_v2"]))
+        euclid = bool(variant == "livenote_v2" and rs.rand() < 0.4)
+        mode = "set_live" if rs.rand() < 0.3 else "insert"
+        waves = int(rs.choice([1, 2, 4, 8]))
+        batch = int(rs.choice([1, 3]))
+        if rs.rand() < 0.25:
+            ref, base_live = synth.synth_tie(max(n_ref, 2), seed=trial)
+            n_ref = ref.shape[1]
+        else:
+            ref = synth.synth_ref(n_ref, seed=trial)
+            base_live = None
+        lives = []
+        for b in range(batch):
+            if base_live is not None:
+                lv = base_live
+            else:
+                lv = synth.synth_live(ref, seed=1000 * trial + b, lo=float(rs.uniform(0.3, 1.0)), hi=float(rs.uniform(1.0, 2.5)))
+                if lv.shape[1] == 0:
+                    lv = ref[:, :1].copy()
+            extra = int(rs.choice([0, 0, 1, 5, 3 * n_ref]))        # run past the reference end / into overflow
+            if extra:
+                lv = np.concatenate([lv, np.repeat(lv[:, -1:], extra, axis=1)], axis=1)
+                lv = synth._as_f32_values(lv + 1e-3 * rs.rand(*lv.shape))
+            if euclid:
+                lv = synth._as_f32_values(np.abs(lv - 0.2))
+            lives.append(lv)
+        refx = synth._as_f32_values(np.abs(ref - 0.2)) if euclid else ref
+        eng = ob.BatchedOTW(refx, c, mrc, batch=batch, variant=variant, euclid=euclid, dtype=torch.float64, waves=waves)
+        lvd, lnd = eng.pack(lives, dtype=torch.float64)
+        eng.run(lvd, lnd, mode=mode)
+        for b, lv in enumerate(lives):
+            o = oracle.OtwOracle(refx, c, mrc, vmap[variant], oracle.COST_EUCLID if euclid else oracle.COST_DOT)
+            if mode == "set_live":
+                o.set_live(lv)
+            else:
+                o.run(lv)
+            tag = (trial, b, n_ref, c, mrc, variant, euclid, mode, waves, lv.shape[1])
+            st, so = eng.state(b), o.state
+            assert np.array_equal(eng.path(b), o.path), tag
+            for key in ("t", "j", "previous", "run_count", "status"):
+                assert st[key] == so[key], (tag, key)
+            if mode == "insert":
+                assert st["direction"] == so["direction"], tag
+                rb, cb = eng.bands(b)
+                orb, ocb = o.bands()
+                assert np.array_equal(rb, orb, equal_nan=True) and np.array_equal(cb, ocb, equal_nan=True), tag
+            checked += 1
+        eng.close()
+    assert checked >= 90
