@@ -85,7 +85,10 @@ __global__ void __launch_bounds__(1024) wtw_advance_kernel(WtwArgs g) {
     int32_t *st = g.state + (size_t)b * 8;
     const double *live = g.live + (size_t)b * g.N * kWF;
     int8_t *Bm = (W <= kWtwLdsB) ? bl : (g.bwork + (size_t)b * W * W);
-    const int appended = g.appended[b];
+    // `appended` may exceed the capacity N: the excess columns were dropped by the append kernel and mean
+    // "the next column does not fit" (wtw.py:92 would raise IndexError) once the stored ones are consumed
+    const int appended_raw = g.appended[b];
+    const int appended = appended_raw < g.N ? appended_raw : g.N;
 
     if (tid == 0) {
         s_chroma_ptr = st[0];
@@ -225,6 +228,7 @@ __global__ void __launch_bounds__(1024) wtw_advance_kernel(WtwArgs g) {
     }
     __syncthreads();
     if (tid == 0) {
+        if (s_status == RTS_RUNNING && s_chroma_ptr >= g.N && appended_raw > g.N) s_status = RTS_LIVE_OVERFLOW;
         st[0] = s_chroma_ptr;
         st[1] = s_live_ptr;
         st[2] = s_ref_ptr;
@@ -245,13 +249,15 @@ __global__ void wtw_precheck_kernel(int32_t *state, int B, int M, int N) {
 }
 
 // Append n_new[b] columns from cols [B][n_max][F] to the live history; columns beyond the 2M capacity
-// are dropped (the reference would raise IndexError) and flagged through status LIVE_OVERFLOW.
+// are dropped (the reference would raise IndexError at that column) and reported as status
+// LIVE_OVERFLOW by the advance kernel once it has walked the columns that did fit.
 __global__ void wtw_append_kernel(double *live, int32_t *appended, int32_t *state, const void *cols, int cols_f64,
                                   const int32_t *n_new, int n_uniform, int n_max, int B, int N) {
     const int b = blockIdx.x;
     if (b >= B) return;
     const int nn = n_new ? n_new[b] : n_uniform;
-    const int base = appended[b];
+    const int base_raw = appended[b];
+    const int base = base_raw < N ? base_raw : N;
     const int running = state[(size_t)b * 8 + 3] == RTS_RUNNING;
     __syncthreads();
     if (!running) return;  // sticky stop: later columns are ignored
@@ -264,10 +270,7 @@ __global__ void wtw_append_kernel(double *live, int32_t *appended, int32_t *stat
         live[((size_t)b * N + base) * kWF + idx] = v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        appended[b] = base + take;
-        if (take < nn) state[(size_t)b * 8 + 3] = RTS_LIVE_OVERFLOW;
-    }
+    if (threadIdx.x == 0 && nn > 0) appended[b] = (take < nn) ? N + 1 : base + take;  // N+1: a column was dropped
 }
 
 }  // namespace rts

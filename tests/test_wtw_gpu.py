@@ -142,6 +142,52 @@ def test_config5_window_10000():
     eng.close()
 
 
+def test_randomized_small_windows():
+    """Seeded sweep: window sizes from 1 frame up, hops from 1 to W, references barely longer than a
+    window, live streams shorter / longer than the reference, silent (all-zero) frames -> NaN costs."""
+    import oracle
+    from real_time_audio_sync_amd import synth
+    from real_time_audio_sync_amd.wtw import BatchedWTW
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(77)
+    for trial in range(40):
+        W = int(rs.choice([1, 2, 3, 5, 8, 16, 20, 33, 64, 127, 128, 129, 200]))
+        hopf = int(rs.randint(1, W + 1))
+        M = int(W + rs.choice([1, 2, 3, 10, 60, 150]))
+        ref = synth.synth_ref(M, seed=trial)
+        live = synth.synth_live(ref, seed=500 + trial, lo=float(rs.uniform(0.5, 1.0)), hi=float(rs.uniform(1.0, 2.0)))
+        if live.shape[1] == 0:
+            live = ref[:, :1].copy()
+        extra = int(rs.choice([0, 0, W, 2 * M]))
+        if extra:
+            live = np.concatenate([live, np.repeat(live[:, -1:], extra, axis=1)], axis=1)
+        live = live * (0.5 + rs.rand(1, live.shape[1]))       # un-normalised columns
+        if rs.rand() < 0.3 and live.shape[1] > 3:
+            live[:, int(rs.randint(0, live.shape[1]))] = 0.0   # a silent frame (wtw.py:169 divides by zero)
+        eng = BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev), W, hopf, 1)
+        cut = int(rs.randint(0, live.shape[1] + 1))
+        cols = torch.from_numpy(np.ascontiguousarray(live.T))[None].to(dev)
+        if cut > 0:
+            eng.push(cols[:, :cut].contiguous(), precheck=True)
+        if cut < live.shape[1]:
+            eng.push(cols[:, cut:].contiguous(), precheck=True)
+        o = oracle.WtwOracle(ref, W, hopf)
+        with np.errstate(all="ignore"):
+            for q in range(live.shape[1]):
+                # the drop-in applies insert()'s entry check once per push; the oracle mirrors that
+                if q == 0 or q == cut:
+                    if o.insert_precheck() != oracle.RUNNING:
+                        break
+                if o.push_col(live[:, q]) != oracle.RUNNING:
+                    break
+        st, so = eng.state(), o.state
+        tag = (trial, W, hopf, M, live.shape[1], cut)
+        assert np.array_equal(eng.path(), o.path), tag
+        assert (st["live_ptr"], st["ref_ptr"], st["windows"]) == (so["live_ptr"], so["ref_ptr"], o.counters["windows"]), tag
+        assert (st["status"] != 0) == (so["status"] != 0), tag
+        eng.close()
+
+
 def test_wtw_argument_errors():
     from real_time_audio_sync_amd import _native as nat
     from real_time_audio_sync_amd.wtw import BatchedWTW
