@@ -54,7 +54,10 @@ struct OtwArgs {
     double *dense_cost;       // optional [B][2N][N]: the reference's dense cost (otw_eran.py:23)
 };
 
-template <int W>
+// RT = element type of the feature rings: double, or float when both inputs are float32 (their values
+// widen back exactly, so results are identical while the workgroup's LDS drops from 131 KB to 74 KB at
+// W = 512 and two workgroups share a CU -- what matters beyond 256 concurrent streams).
+template <int W, typename RT>
 struct OtwLds {
     static constexpr int L = W / 64;     // cells per lane in the chain phase
     static constexpr int SWZ = L * 65;   // swizzled band length (one pad slot per row of 64)
@@ -62,8 +65,8 @@ struct OtwLds {
     double C[SWZ];      // acc[.][j]  column band
     double Dr[2][SWZ];  // row strip cell costs: [buf] = this step's, [buf^1] = being pre-computed for the next
     double Dc[2][SWZ];
-    double refw[kF][W];   // feature-major ring of reference frames (index y & (W-1))
-    double livew[kF][W];  // feature-major ring of live frames      (index x & (W-1))
+    RT refw[kF][W];   // feature-major ring of reference frames (index y & (W-1))
+    RT livew[kF][W];  // feature-major ring of live frames      (index x & (W-1))
     // column chain wave -> wave 0, read back in one go
     double cfresh_min;
     double corner_pa;  // Both step: acc[t-1][jn-1] + 2 d(t, jn), stashed before column jn-1 is overwritten
@@ -360,21 +363,21 @@ __device__ __forceinline__ void otw_prefetch_ref(OtwCtl &k, const OtwEnv &e) {
     if (f0 < e.N) k.pfr0 = otw_load_feat(e.ref, e.ref_f64, (long long)f0 * kF + i0 % kF);
     if (i1 < kFetch * kF && f1 < e.N) k.pfr1 = otw_load_feat(e.ref, e.ref_f64, (long long)f1 * kF + i1 % kF);
 }
-template <int W>
-__device__ __forceinline__ void otw_commit_live(OtwLds<W> &S, OtwCtl &k, const OtwEnv &e) {
+template <int W, typename RT>
+__device__ __forceinline__ void otw_commit_live(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e) {
     const int i0 = e.lane, i1 = e.lane + 64;
     const int f0 = k.live_hi + 1 + i0 / kF, f1 = k.live_hi + 1 + i1 / kF;
-    if (f0 < e.live_len) S.livew[i0 % kF][f0 & (W - 1)] = k.pfl0;
-    if (i1 < kFetch * kF && f1 < e.live_len) S.livew[i1 % kF][f1 & (W - 1)] = k.pfl1;
+    if (f0 < e.live_len) S.livew[i0 % kF][f0 & (W - 1)] = (RT)k.pfl0;
+    if (i1 < kFetch * kF && f1 < e.live_len) S.livew[i1 % kF][f1 & (W - 1)] = (RT)k.pfl1;
     k.live_hi = (k.live_hi + kFetch < e.live_len - 1) ? k.live_hi + kFetch : e.live_len - 1;
     otw_prefetch_live(k, e);
 }
-template <int W>
-__device__ __forceinline__ void otw_commit_ref(OtwLds<W> &S, OtwCtl &k, const OtwEnv &e) {
+template <int W, typename RT>
+__device__ __forceinline__ void otw_commit_ref(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e) {
     const int i0 = e.lane, i1 = e.lane + 64;
     const int f0 = k.ref_hi + 1 + i0 / kF, f1 = k.ref_hi + 1 + i1 / kF;
-    if (f0 < e.N) S.refw[i0 % kF][f0 & (W - 1)] = k.pfr0;
-    if (i1 < kFetch * kF && f1 < e.N) S.refw[i1 % kF][f1 & (W - 1)] = k.pfr1;
+    if (f0 < e.N) S.refw[i0 % kF][f0 & (W - 1)] = (RT)k.pfr0;
+    if (i1 < kFetch * kF && f1 < e.N) S.refw[i1 % kF][f1 & (W - 1)] = (RT)k.pfr1;
     k.ref_hi = (k.ref_hi + kFetch < e.N - 1) ? k.ref_hi + kFetch : e.N - 1;
     otw_prefetch_ref(k, e);
 }
@@ -382,8 +385,8 @@ __device__ __forceinline__ void otw_commit_ref(OtwLds<W> &S, OtwCtl &k, const Ot
 // Speculative costs for the step after the one that leaves the state at (t_now, j_now): row t_now+1
 // over columns [j_now-c+1, j_now] and column j_now+1 over rows [t_now-c+1, t_now+1] cover every
 // possible next step (Row, Both or Column).  hidx / hn: index and count of the threads sharing it.
-template <int W>
-__device__ __forceinline__ void otw_precompute(OtwLds<W> &S, const OtwEnv &e, int t_now, int j_now, double *Drn,
+template <int W, typename RT>
+__device__ __forceinline__ void otw_precompute(OtwLds<W, RT> &S, const OtwEnv &e, int t_now, int j_now, double *Drn,
                                                double *Dcn, int hidx, int hn) {
     const int c = e.c;
     const int tn = t_now + 1, jn1 = j_now + 1;
@@ -397,24 +400,24 @@ __device__ __forceinline__ void otw_precompute(OtwLds<W> &S, const OtwEnv &e, in
     if (nrow > 0) {
         double lf[kF];
 #pragma unroll
-        for (int f = 0; f < kF; f++) lf[f] = S.livew[f][tn & (W - 1)];
+        for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][tn & (W - 1)];
         for (int i = hidx; i < nrow; i += hn) {
             const int k = k1 + i;
             double rf[kF];
 #pragma unroll
-            for (int f = 0; f < kF; f++) rf[f] = S.refw[f][k & (W - 1)];
+            for (int f = 0; f < kF; f++) rf[f] = (double)S.refw[f][k & (W - 1)];
             Drn[swz<W>(k)] = cell_cost(lf, rf, e.euclid);
         }
     }
     if (ncol > 0) {
         double rf[kF];
 #pragma unroll
-        for (int f = 0; f < kF; f++) rf[f] = S.refw[f][jn1 & (W - 1)];
+        for (int f = 0; f < kF; f++) rf[f] = (double)S.refw[f][jn1 & (W - 1)];
         for (int i = hidx; i < ncol; i += hn) {
             const int r = r1 + i;
             double lf[kF];
 #pragma unroll
-            for (int f = 0; f < kF; f++) lf[f] = S.livew[f][r & (W - 1)];
+            for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][r & (W - 1)];
             Dcn[swz<W>(r)] = cell_cost(lf, rf, e.euclid);
         }
     }
@@ -425,8 +428,8 @@ __device__ __forceinline__ void otw_precompute(OtwLds<W> &S, const OtwEnv &e, in
 // step brings its own argmin from its chain; a band that merely slid by one cell keeps its minimum
 // unless that cell left the window (then a full wave reduction recomputes it); the one cell
 // appended at the top index wins only if strictly smaller (np.argmin returns the first minimum).
-template <int W>
-__device__ __forceinline__ void otw_decide(OtwLds<W> &S, OtwCtl &k, const OtwEnv &e, int tt, int jj, bool row_fresh,
+template <int W, typename RT>
+__device__ __forceinline__ void otw_decide(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, int tt, int jj, bool row_fresh,
                                            double rf_min, int rf_idx, bool col_fresh, double cf_min, int cf_idx,
                                            bool row_corner, double rc, bool col_corner, double cc, bool full) {
     const int c = e.c;
@@ -518,8 +521,8 @@ __device__ __forceinline__ void otw_decide(OtwLds<W> &S, OtwCtl &k, const OtwEnv
 }
 
 // Plan for the next step from the current register state (wave 0); lane 0 publishes it.
-template <int W>
-__device__ __forceinline__ void otw_make_plan(OtwLds<W> &S, OtwCtl &k, const OtwEnv &e) {
+template <int W, typename RT>
+__device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e) {
     int flags = 0, pt = k.t;
     if (k.status != RTS_RUNNING) {
         flags = kPlanExit;
@@ -552,12 +555,12 @@ __device__ __forceinline__ void otw_make_plan(OtwLds<W> &S, OtwCtl &k, const Otw
         const int jn_p = k.j + ((flags & kPlanCol) ? 1 : 0);
         const int need_l = (pt + 1 < e.live_len - 1) ? pt + 1 : e.live_len - 1;
         const int need_r = (jn_p + 1 < e.N - 1) ? jn_p + 1 : e.N - 1;
-        if (need_l > k.live_hi) otw_commit_live<W>(S, k, e);
-        if (need_r > k.ref_hi) otw_commit_ref<W>(S, k, e);
+        if (need_l > k.live_hi) otw_commit_live<W, RT>(S, k, e);
+        if (need_r > k.ref_hi) otw_commit_ref<W, RT>(S, k, e);
     }
 }
 
-template <int W, int NW, bool DENSE>
+template <int W, int NW, bool DENSE, typename RT>
 __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     constexpr int NT = 64 * NW;
     // Waves >= HW0 pre-compute the next step's cell costs while waves 0/1 run the chains.  With fewer
@@ -570,7 +573,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    OtwLds<W> &S = *reinterpret_cast<OtwLds<W> *>(smem_raw);
+    OtwLds<W, RT> &S = *reinterpret_cast<OtwLds<W, RT> *>(smem_raw);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     if (live_len <= k.consumed) return;  // nothing new
 
     // ---- prologue: windows (synchronous fill by all threads), persisted bands, first frame
-    for (int i = tid; i < OtwLds<W>::SWZ; i += NT) {  // no uninitialised LDS ever reaches the arithmetic
+    for (int i = tid; i < OtwLds<W, RT>::SWZ; i += NT) {  // no uninitialised LDS ever reaches the arithmetic
         S.R[i] = 0.0;
         S.C[i] = 0.0;
         S.Dr[0][i] = S.Dr[1][i] = S.Dc[0][i] = S.Dc[1][i] = 0.0;
@@ -659,11 +662,11 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         k.ref_hi = (k.j + 2 < N - 1) ? k.j + 2 : N - 1;
         for (int idx = tid; idx < (k.live_hi - lo_l + 1) * kF; idx += NT) {
             const int fr = lo_l + idx / kF, f = idx % kF;
-            S.livew[f][fr & (W - 1)] = otw_load_feat(a.live, a.live_f64, e.live_base + (long long)fr * kF + f);
+            S.livew[f][fr & (W - 1)] = (RT)otw_load_feat(a.live, a.live_f64, e.live_base + (long long)fr * kF + f);
         }
         for (int idx = tid; idx < (k.ref_hi - lo_r + 1) * kF; idx += NT) {
             const int fr = lo_r + idx / kF, f = idx % kF;
-            S.refw[f][fr & (W - 1)] = otw_load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
+            S.refw[f][fr & (W - 1)] = (RT)otw_load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
         }
         if (!k.first) {
             const double *bb = a.bands + (size_t)e.b * 2 * (c + 1);
@@ -682,8 +685,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             double lf[kF], rf[kF];
 #pragma unroll
             for (int f = 0; f < kF; f++) {
-                lf[f] = S.livew[f][0];
-                rf[f] = S.refw[f][0];
+                lf[f] = (double)S.livew[f][0];
+                rf[f] = (double)S.refw[f][0];
             }
             const double d = rfl(cell_cost(lf, rf, e.euclid));
             if (lane == 0) {
@@ -706,7 +709,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             k.cb_idx = 0;
             __builtin_amdgcn_wave_barrier();
             if (a.mode == RTS_MODE_SET_LIVE)
-                otw_decide<W>(S, k, e, 0, 0, false, 0.0, 0, false, 0.0, 0, false, 0.0, false, 0.0, true);
+                otw_decide<W, RT>(S, k, e, 0, 0, false, 0.0, 0, false, 0.0, 0, false, 0.0, false, 0.0, true);
         } else {  // band minima are not persisted: rebuild them from the reloaded bands
             for (int which = 0; which < 2; which++) {
                 const int hi = which ? k.t : k.j;
@@ -730,8 +733,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     __syncthreads();
     // prime the cost buffers for the first step (all threads), then publish its plan
     int buf = 0;
-    otw_precompute<W>(S, e, S.t, S.j, S.Dr[0], S.Dc[0], tid, NT);
-    if (wave == 0) otw_make_plan<W>(S, k, e);
+    otw_precompute<W, RT>(S, e, S.t, S.j, S.Dr[0], S.Dc[0], tid, NT);
+    if (wave == 0) otw_make_plan<W, RT>(S, k, e);
     __syncthreads();
 
     // ---- step loop: one iteration = one row strip and/or one column strip + one decide()
@@ -782,7 +785,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         }
         RTS_STAMP(3);
         if (!stop && wave >= HW0)
-            otw_precompute<W>(S, e, pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
+            otw_precompute<W, RT>(S, e, pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
         RTS_STAMP(4);
         __syncthreads();
         RTS_STAMP(5);
@@ -836,11 +839,11 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 // row band: fresh from this step's row strip, plus the corner a column strip appended;
                 // column band: fresh from this step's column strip (its corner cell is outside the
                 // chain), or the old band plus the row strip's last cell
-                otw_decide<W>(S, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl,
+                otw_decide<W, RT>(S, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl,
                               do_row, col_active ? cl : row_last, false);
             }
             RTS_STAMP(7);
-            otw_make_plan<W>(S, k, e);
+            otw_make_plan<W, RT>(S, k, e);
         }
         RTS_STAMP(8);
         __syncthreads();
@@ -965,16 +968,16 @@ struct rts_otw {
 
 namespace rts {
 
-template <int W, int NW, bool DENSE>
+template <int W, int NW, bool DENSE, typename RT>
 static int launch_advance_d(const OtwArgs &args, int B, hipStream_t s) {
-    const size_t smem = sizeof(OtwLds<W>);
+    const size_t smem = sizeof(OtwLds<W, RT>);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
-        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&otw_advance_kernel<W, NW, DENSE>),
+        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&otw_advance_kernel<W, NW, DENSE, RT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
-    hipLaunchKernelGGL((otw_advance_kernel<W, NW, DENSE>), dim3(B), dim3(64 * NW), smem, s, args);
+    hipLaunchKernelGGL((otw_advance_kernel<W, NW, DENSE, RT>), dim3(B), dim3(64 * NW), smem, s, args);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -982,7 +985,10 @@ static int launch_advance_d(const OtwArgs &args, int B, hipStream_t s) {
 // The dense mirror is a separate instantiation so that the default kernel carries none of its code.
 template <int W, int NW>
 static int launch_advance(const OtwArgs &args, int B, hipStream_t s) {
-    return args.dense_acc ? launch_advance_d<W, NW, true>(args, B, s) : launch_advance_d<W, NW, false>(args, B, s);
+    if (args.dense_acc) return launch_advance_d<W, NW, true, double>(args, B, s);
+    // float32 rings only when both inputs are float32: every value then widens back exactly
+    if (!args.ref_f64 && !args.live_f64) return launch_advance_d<W, NW, false, float>(args, B, s);
+    return launch_advance_d<W, NW, false, double>(args, B, s);
 }
 
 template <int W>
