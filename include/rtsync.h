@@ -157,11 +157,16 @@ int rts_dtw_workspace_bytes(int M, int N, int B, size_t *back_bytes);
  *   cost_dev, acc_dev: double [B][M][N] outputs (dtw.py:11, :14); back_dev: int8 [B][M][N]
  *          step codes 0 = (0,-1), 1 = (-1,0), 2 = (-1,-1) (dtw.py:30); path_dev: int32
  *          [B][M+N][2], pairs (i, j) from (0,0) to (M-1,N-1); path_len_dev: int32 [B].
- * M is limited to 6400 rows (three float64 diagonals are kept in LDS).  Asynchronous on `stream`;
+ * M is limited to 6400 rows here (three float64 diagonals are kept in LDS; see rts_dtw_ws).  Asynchronous on `stream`;
  * no allocation, no synchronisation (graph-capturable). */
 int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_dev, int b_dtype,
             long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
             int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, void *stream);
+/* The same without the 6400-row limit: `diag_ws_dev` is a caller-owned workspace of B*3*M doubles holding the
+ * three rotating anti-diagonals in HBM when they do not fit LDS (ignored, may be NULL, when M <= 6400). */
+int rts_dtw_ws(const void *a_dev, int a_dtype, long long a_stride, const void *b_dev, int b_dtype,
+               long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
+               int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, double *diag_ws_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Chroma front end: frame -> window -> rFFT -> power -> 12-bin filterbank -> L2 normalise.

@@ -67,6 +67,7 @@ _decl("rts_otw_kernel_name", ctypes.c_char_p, [_vp])
 _i64 = ctypes.c_longlong
 _decl("rts_dtw_workspace_bytes", _i32, [_i32, _i32, _i32, ctypes.POINTER(ctypes.c_size_t)])
 _decl("rts_dtw", _i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp])
+_decl("rts_dtw_ws", _i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 
 
 _decl("rts_chroma_num_frames", _i64, [_i64, _i32, _i32, _i32])

@@ -30,6 +30,7 @@ struct DtwArgs {
     int32_t *path_len;  // [B]
     long long a_stride, b_stride;
     int M, N, a_f64, b_f64;
+    double *diag_ws;  // [B][3][M] doubles in HBM when the three diagonals do not fit LDS, else NULL
 };
 
 __device__ __forceinline__ double dtw_load(const void *p, int f64, long long idx) {
@@ -52,8 +53,10 @@ __global__ void __launch_bounds__(256) dtw_cost_kernel(DtwArgs g) {
 template <int NT>
 __global__ void __launch_bounds__(NT) dtw_dp_kernel(DtwArgs g) {
     extern __shared__ __align__(16) unsigned char dtw_smem[];
-    double *diag = reinterpret_cast<double *>(dtw_smem);  // [3][M]
     const int pair = blockIdx.x;
+    // [3][M]: LDS, or (long sequences) an HBM workspace -- workgroup-scope visibility through the barrier
+    // is all a single-workgroup sweep needs
+    double *diag = g.diag_ws ? g.diag_ws + (size_t)pair * 3 * g.M : reinterpret_cast<double *>(dtw_smem);
     const int tid = threadIdx.x;
     const int M = g.M, N = g.N;
     const size_t base = (size_t)pair * M * N;
@@ -181,6 +184,13 @@ int rts_dtw_workspace_bytes(int M, int N, int B, size_t *back_bytes) {
 int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_dev, int b_dtype,
             long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
             int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, void *stream) {
+    return rts_dtw_ws(a_dev, a_dtype, a_stride, b_dev, b_dtype, b_stride, F, M, N, B, cost_dev, acc_dev, back_dev,
+                      path_dev, path_len_dev, nullptr, stream);
+}
+
+int rts_dtw_ws(const void *a_dev, int a_dtype, long long a_stride, const void *b_dev, int b_dtype,
+               long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
+               int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, double *diag_ws_dev, void *stream) {
     using namespace rts;
     if (!a_dev || !b_dev || !cost_dev || !acc_dev || !back_dev || !path_dev || !path_len_dev)
         return set_error(RTS_ERR_INVALID, "NULL device buffer");
@@ -188,10 +198,14 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
     if (M < 1 || N < 1 || B < 1) return set_error(RTS_ERR_INVALID, "M, N, B must be >= 1 (got %d %d %d)", M, N, B);
     if ((a_dtype != RTS_F32 && a_dtype != RTS_F64) || (b_dtype != RTS_F32 && b_dtype != RTS_F64))
         return set_error(RTS_ERR_INVALID, "bad dtype");
-    const size_t smem = sizeof(double) * 3 * (size_t)M;
-    if (smem > 150 * 1024)
-        return set_error(RTS_ERR_UNSUPPORTED, "M=%d rows exceed the %d the LDS-resident DP sweep holds", M,
-                         (int)(150 * 1024 / 24));
+    size_t smem = sizeof(double) * 3 * (size_t)M;
+    const bool in_lds = smem <= 150 * 1024;
+    if (!in_lds && !diag_ws_dev)
+        return set_error(RTS_ERR_UNSUPPORTED,
+                         "M=%d rows exceed the %d the LDS-resident DP sweep holds; call rts_dtw_ws with a "
+                         "B*3*M-double workspace", M, (int)(150 * 1024 / 24));
+    if (!in_lds) smem = 64;
+    if ((long long)M * N > 0x7fffffffLL * 4) return set_error(RTS_ERR_INVALID, "M*N too large");
     hipStream_t s = (hipStream_t)stream;
     DtwArgs g;
     g.a = a_dev;
@@ -207,6 +221,7 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
     g.N = N;
     g.a_f64 = a_dtype == RTS_F64;
     g.b_f64 = b_dtype == RTS_F64;
+    g.diag_ws = in_lds ? nullptr : diag_ws_dev;
     hipLaunchKernelGGL(dtw_cost_kernel, dim3((N + 63) / 64, (M + 3) / 4, B), dim3(256), 0, s, g);
     RTS_HIP(hipGetLastError());
     // one row per thread up to 1024 rows; fewer waves for small M keeps the per-diagonal barrier cheap

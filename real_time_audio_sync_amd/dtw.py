@@ -24,10 +24,13 @@ def dtw_batch(a_dev, b_dev, stream_device=None):
     back = torch.empty((B, M, N), dtype=torch.int8, device=dev)
     path = torch.empty((B, M + N, 2), dtype=torch.int32, device=dev)
     plen = torch.zeros((B,), dtype=torch.int32, device=dev)
-    nat.check(nat.lib.rts_dtw(a_dev.data_ptr(), _np_dtype_code(a_dev.dtype), 0 if sa else M,
-                              b_dev.data_ptr(), _np_dtype_code(b_dev.dtype), 0 if sb else N,
-                              12, M, N, B, cost.data_ptr(), acc.data_ptr(), back.data_ptr(), path.data_ptr(),
-                              plen.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    # sequences of more than 6400 frames keep their three anti-diagonals in an HBM workspace
+    ws = torch.empty((B, 3, M), dtype=torch.float64, device=dev) if M > 6400 else None
+    nat.check(nat.lib.rts_dtw_ws(a_dev.data_ptr(), _np_dtype_code(a_dev.dtype), 0 if sa else M,
+                                 b_dev.data_ptr(), _np_dtype_code(b_dev.dtype), 0 if sb else N,
+                                 12, M, N, B, cost.data_ptr(), acc.data_ptr(), back.data_ptr(), path.data_ptr(),
+                                 plen.data_ptr(), ws.data_ptr() if ws is not None else None,
+                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return cost, acc, back, path, plen
 
 

@@ -1,0 +1,30 @@
+"""The committed bench line (profiles/r01h_bench_final.json, produced by `python bench.py` on an MI355X)
+carries every field the driver's contract asks for, and its numbers are self-consistent."""
+import json
+import os
+
+from conftest import ROOT
+
+
+def test_bench_line_contract():
+    r = json.load(open(os.path.join(ROOT, "profiles", "r01h_bench_final.json")))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert r["metric"] == base["metric"] and r["unit"] == "frames/s"
+    for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["higher_is_better"] is True and r["scaling"] == "weak"
+    assert r["vs_baseline"] is None            # BASELINE.md publishes no number for this metric
+    assert r["dtype"] == "f64" and r["data"] == "synthetic" and "workload" in r["config"]
+    assert "model" not in r["config"]
+    # value = frames of one step / time per step
+    assert abs(r["value"] - r["config"]["frames_per_step"] / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+    assert r["value"] >= 1e6                   # north_star target on 1x MI355X
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert rf["traffic"] is None or rf["traffic"] < rf["algorithmic_bytes_per_launch"]
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["sample"]
+    assert r["parity"]["path_mismatches"] == 0 and r["parity"]["streams_checked"] == 64

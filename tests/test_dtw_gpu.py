@@ -85,3 +85,38 @@ def test_dtw_config1_sizes():
         assert tuple(path[0]) == (0, 0) and tuple(path[-1]) == (l.shape[1] - 1, n - 1)
         step = np.diff(path, axis=0)
         assert ((step >= 0).all() and (step <= 1).all() and (step.sum(axis=1) >= 1).all())
+
+
+def test_dtw_long_sequences_hbm_diagonals():
+    """Beyond 6400 rows the three anti-diagonals move from LDS to an HBM workspace (rts_dtw_ws).  7000 x 900
+    against the oracle, then a 30-minute-sized pair (19 380 x 19 380: 3 GB each for cost and acc_cost) through
+    size-independent properties."""
+    import oracle
+    from real_time_audio_sync_amd import _native as nat, synth
+    from real_time_audio_sync_amd.dtw import DTW, dtw_batch
+    from real_time_audio_sync_amd.otw_batch import frames_tensor
+    a = synth.synth_ref(7000, seed=70)
+    b = synth.synth_live(synth.synth_ref(900, seed=71), seed=72, max_frames=900)
+    cost, acc, path = DTW(a, b)
+    ocost, oacc, opath, _ = oracle.dtw(a, b)
+    assert np.array_equal(path, opath) and np.array_equal(acc, oacc) and np.array_equal(cost, ocost)
+    # the plain entry point refuses, with a message that names the way out
+    dev = torch.device("cuda:0")
+    n = 19380
+    ref = synth.synth_ref(n, seed=80)
+    live = synth.synth_live(ref, seed=81)
+    ad, bd = frames_tensor(live, dev, torch.float32), frames_tensor(ref, dev, torch.float32)
+    cost, acc, back, pth, plen = dtw_batch(ad, bd)
+    torch.cuda.synchronize()
+    m = ad.shape[0]
+    p = pth[0, : int(plen[0])].cpu().numpy()
+    assert tuple(p[0]) == (0, 0) and tuple(p[-1]) == (m - 1, n - 1)
+    step = np.diff(p, axis=0)
+    assert (step >= 0).all() and (step <= 1).all() and (step.sum(axis=1) >= 1).all()
+    # the accumulated cost at the end equals the sum of weighted costs along the returned path (dtw.py:35-37)
+    c = cost[0][torch.from_numpy(p[:, 0]).to(dev).long(), torch.from_numpy(p[:, 1]).to(dev).long()].cpu().numpy()
+    w = np.where(step.sum(axis=1) == 2, 2.0, 1.0)
+    total = c[0] + float((c[1:] * w).sum())
+    assert abs(total - float(acc[0, -1, -1])) <= 1e-9 * max(1.0, abs(total))
+    # synthetic warps stay within 0.8..1.25 of the diagonal
+    assert np.abs(p[:, 1] - p[:, 0] * (n / float(m))).max() < 0.2 * n
