@@ -23,20 +23,18 @@ def read_ground_truth(csv_path):
 
 
 def get_beat(sample, gt_times, gt_beats, frame_seconds=FRAME_SECONDS):
-    """Fractional beat of chroma frame ``sample`` by linear interpolation (tests.py:112-128)."""
-    time = sample * frame_seconds
-    for i in range(len(gt_times)):
-        if i == 0:
-            if time <= gt_times[i]:
-                if gt_times[i] != 0:
-                    frac = float(gt_times[i] - time) / (gt_times[i] - 0)
-                else:
-                    frac = 0
-                return gt_beats[i] - frac
-        else:
-            if gt_times[i - 1] <= time <= gt_times[i]:
-                frac = float(gt_times[i] - time) / (gt_times[i] - gt_times[i - 1])
-                return gt_beats[i] - frac
+    """Fractional beat of chroma frame ``sample``: linear interpolation between annotated beat times,
+    the stretch before the first annotation being interpolated from time zero; None past the last
+    annotation.  Same arithmetic as tests.py:112-128: beat_i - (t_i - t) / (t_i - t_{i-1})."""
+    t = sample * frame_seconds
+    seg_start = 0.0  # the first segment starts at time zero, later ones at the previous annotation
+    for i, (seg_end, beat) in enumerate(zip(gt_times, gt_beats)):
+        inside = (t <= seg_end) if i == 0 else (seg_start <= t <= seg_end)
+        if inside:
+            if i == 0 and seg_end == 0:
+                return beat - 0
+            return beat - float(seg_end - t) / (seg_end - seg_start)
+        seg_start = seg_end
     return None
 
 
@@ -52,10 +50,14 @@ class AlignmentError(object):
         self.path = path
 
     def get_time(self, beat):
-        time = self.live_gt_times[int(beat)]
-        if int(beat) + 1 < len(self.live_gt_times):
-            time += (beat % 1) * (self.live_gt_times[int(beat) + 1] - self.live_gt_times[int(beat)])
-        return time
+        """Seconds for a fractional beat, read off the *live* annotation with the beat's integer part used
+        directly as the list index (the reference's convention, tests.py:130-134)."""
+        times = self.live_gt_times
+        whole = int(beat)
+        seconds = times[whole]
+        if whole + 1 < len(times):
+            seconds += (beat % 1) * (times[whole + 1] - times[whole])
+        return seconds
 
     def get_secs_off(self, ref_beat, live_beat):
         return abs(self.get_time(ref_beat) - self.get_time(live_beat))
