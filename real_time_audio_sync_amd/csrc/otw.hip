@@ -560,6 +560,110 @@ __device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const
     }
 }
 
+// This step's row strip (t, [k1r, j0]) on the calling wave; returns its argmin restricted to the row
+// band decide() will look at.
+template <int W, bool DENSE, typename RT>
+__device__ __forceinline__ void otw_row_strip(OtwLds<W, RT> &S, const OtwArgs &a, const OtwEnv &e, const double *Dr,
+                                              int pt, int j0, int jn, double sentinel, double &rf_min, int &rf_idx) {
+    const int c = e.c;
+    const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, nr = j0 - k1r + 1;
+    const double x_in = (k1r > 0) ? sentinel : (double)INFINITY;  // (t, k1r-1) was never evaluated
+    const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;        // row band's lower end at decide()
+    const long long dro = ((long long)e.b * e.live_cap + pt) * e.N + k1r;  // cell (pt, k1r)
+    strip_chain<W, DENSE>(Dr, S.R, k1r, nr, x_in, e.lane, lo_arg, rf_min, rf_idx, DENSE ? a.dense_acc + dro : nullptr,
+                          DENSE ? a.dense_cost + dro : nullptr, 1);
+    if (e.lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
+}
+
+// This step's column strip ([k1c, pt or pt-1], jn) on the calling wave; in a Both step (with_row) the corner
+// cell (pt, jn) is left to the fix-up and its diagonal term is stashed before column jn-1 is overwritten.
+template <int W, bool DENSE, typename RT>
+__device__ __forceinline__ void otw_col_strip(OtwLds<W, RT> &S, const OtwArgs &a, const OtwEnv &e, const double *Dc,
+                                              int pt, int jn, bool with_row, double sentinel) {
+    const int c = e.c;
+    const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1;
+    const double x_in = (k1c > 0) ? sentinel : (double)INFINITY;  // (k1c-1, jn) was never evaluated
+    const int ncc = nc - (with_row ? 1 : 0);
+    double fm;
+    int fi;
+    const double dcorner = Dc[swz<W>(pt)];
+    const double pa = (with_row && pt > 0) ? S.C[swz<W>(pt - 1)] + 2 * dcorner : (double)INFINITY;
+    const long long dco = ((long long)e.b * e.live_cap + k1c) * e.N + jn;  // cell (k1c, jn)
+    strip_chain<W, DENSE>(Dc, S.C, k1c, ncc, x_in, e.lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
+                          DENSE ? a.dense_cost + dco : nullptr, e.N);
+    if (e.lane == 0) {
+        S.corner_pa = pa;
+        S.corner_d = dcorner;
+        if (k1c > 0) S.C[swz<W>(k1c - 1)] = sentinel;
+        S.cfresh_min = fm;
+        S.cfresh_idx = fi;
+    }
+}
+
+// Control phase of one step (wave 0): corner fix-up, decide(), next plan.
+template <int W, bool DENSE, typename RT>
+__device__ __forceinline__ void otw_control(OtwLds<W, RT> &S, OtwCtl &k, const OtwArgs &a, const OtwEnv &e,
+                                            int pt, int j0, int pflags, double rf_min, int rf_idx, double sentinel) {
+    const int c = e.c, lane = e.lane;
+    const double inf = INFINITY;
+    const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
+    const bool stop = (pflags & kPlanStop) != 0;
+    const bool col_active = do_col && !stop;
+    const int jn = j0 + (do_col ? 1 : 0);
+    const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, nr = j0 - k1r + 1;
+    const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1;
+    if (!stop && e.deferred_update && k.pend_dir != -2) {  // livenote_v2.py:149-155
+        k.run_count = (k.pend_dir == k.prev) ? k.run_count + 1 : 1;
+        if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
+        k.pend_dir = -2;
+    }
+    if (do_row) {
+        k.rows += 1;
+        k.cells += nr;
+        k.consumed = pt + 1;
+    }
+    double cl = 0.0, cf_min = inf;
+    int cf_idx = 0x7fffffff;
+    // last cell of the row strip = acc[t][j0]; of the column chain = acc[t-1][jn] (Both) or acc[t][jn]
+    const double row_last = do_row ? rfl(S.R[swz<W>(j0)]) : 0.0;
+    if (do_row && !col_active && lane == 0) S.C[swz<W>(pt)] = row_last;  // column j0 gains row t
+    if (col_active) {
+        const int ncc = nc - (do_row ? 1 : 0);
+        cl = (ncc > 0) ? rfl(S.C[swz<W>(k1c + ncc - 1)]) : ((k1c > 0) ? sentinel : inf);
+        cf_min = rfl(S.cfresh_min);
+        cf_idx = __builtin_amdgcn_readfirstlane(S.cfresh_idx);
+        if (do_row) {
+            const double d = rfl(S.corner_d);
+            const double av = vmin(row_last + d, rfl(S.corner_pa));
+            cl = vmin(av, cl + d);  // cl was the value of (t-1, jn), or the sentinel carry
+            if (lane == 0) {
+                S.C[swz<W>(pt)] = cl;
+                if (DENSE) {
+                    const long long o = ((long long)e.b * e.live_cap + pt) * e.N + jn;
+                    a.dense_acc[o] = cl;
+                    a.dense_cost[o] = d;
+                }
+            }
+        }
+        if (lane == 0) S.R[swz<W>(jn)] = cl;  // row t gains column jn
+        k.cols += 1;
+        k.cells += nc;
+    }
+    if (stop) {
+        k.status = RTS_STOP_REF_END;
+        k.t = pt;
+        k.j = jn;
+        k.pending_col = 0;
+    } else {
+        // row band: fresh from this step's row strip, plus the corner a column strip appended;
+        // column band: fresh from this step's column strip (its corner cell is outside the
+        // chain), or the old band plus the row strip's last cell
+        otw_decide<W, RT>(S, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl, do_row,
+                          col_active ? cl : row_last, false);
+    }
+    otw_make_plan<W, RT>(S, k, e);
+}
+
 template <int W, int NW, bool DENSE, typename RT>
 __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     constexpr int NT = 64 * NW;
@@ -737,117 +841,171 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     if (wave == 0) otw_make_plan<W, RT>(S, k, e);
     __syncthreads();
 
-    // ---- step loop: one iteration = one row strip and/or one column strip + one decide()
-    for (;;) {
-        RTS_STAMP(0);
-        const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
-                  pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
-        if (pflags & kPlanExit) break;
-        const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
-        const bool stop = (pflags & kPlanStop) != 0;
-        const int jn = j0 + (do_col ? 1 : 0);
-        const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, nr = j0 - k1r + 1;  // row strip: columns
-        const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1;  // column strip: rows
-        const bool col_active = do_col && !stop;
-        double *Dr = S.Dr[buf], *Dc = S.Dc[buf];
-
-        // -- chain phase: row strip on wave 0, column strip on wave 1; spare waves pre-compute the
-        //    next step's costs meanwhile
-        const int col_wave = (NW > 1 && do_row) ? 1 : 0;
-        double rf_min = inf;
-        int rf_idx = 0x7fffffff;
-        if (do_row && wave == 0) {
-            const double x_in = (k1r > 0) ? sentinel : inf;  // (t, k1r-1) was never evaluated
-            const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // row band's lower end at decide()
-            const long long dro = ((long long)e.b * a.live_cap + pt) * N + k1r;  // cell (pt, k1r)
-            strip_chain<W, DENSE>(Dr, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx, DENSE ? a.dense_acc + dro : nullptr,
-                                  DENSE ? a.dense_cost + dro : nullptr, 1);
-            if (lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
-        }
-        if (col_active && wave == col_wave) {
-            const double x_in = (k1c > 0) ? sentinel : inf;  // (k1c-1, jn) was never evaluated
-            const int ncc = nc - (do_row ? 1 : 0);            // corner cell waits for the row strip
-            double fm;
-            int fi;
-            // the corner's diagonal term needs column jn-1 at row t-1, which the chain is about to overwrite
-            const double dcorner = Dc[swz<W>(pt)];
-            const double pa = (do_row && pt > 0) ? S.C[swz<W>(pt - 1)] + 2 * dcorner : inf;
-            const long long dco = ((long long)e.b * a.live_cap + k1c) * N + jn;  // cell (k1c, jn)
-            strip_chain<W, DENSE>(Dc, S.C, k1c, ncc, x_in, lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
-                                  DENSE ? a.dense_cost + dco : nullptr, N);
-            if (lane == 0) {
-                S.corner_pa = pa;
-                S.corner_d = dcorner;
-                if (k1c > 0) S.C[swz<W>(k1c - 1)] = sentinel;
-                S.cfresh_min = fm;
-                S.cfresh_idx = fi;
+    if constexpr (NW >= 4) {
+        // ---- role-specialised step loops.  Every wave runs only its own role's code between the two barriers of
+        // a step (a step = one row strip and/or one column strip + one decide()), so each loop keeps only its own
+        // values live: helpers pre-compute costs, wave 1 runs the column strip of Both steps, wave 0 runs the
+        // (other) strip and then the control phase.  All of them read the plan wave 0 published.
+        if (wave >= HW0) {
+            for (;;) {
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
+                if (pflags & kPlanExit) break;
+                const int jn = j0 + ((pflags & kPlanCol) ? 1 : 0);
+                if (!(pflags & kPlanStop))
+                    otw_precompute<W, RT>(S, e, pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
+                __syncthreads();  // strips and next costs complete
+                __syncthreads();  // next plan published
+                buf ^= 1;
+            }
+        } else if (wave == 1) {
+            for (;;) {
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
+                if (pflags & kPlanExit) break;
+                if ((pflags & (kPlanRow | kPlanCol | kPlanStop)) == (kPlanRow | kPlanCol))  // Both step
+                    otw_col_strip<W, DENSE, RT>(S, a, e, S.Dc[buf], pt, j0 + 1, true, sentinel);
+                __syncthreads();
+                __syncthreads();
+                buf ^= 1;
+            }
+        } else {
+            for (;;) {
+                RTS_STAMP(0);
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
+                if (pflags & kPlanExit) break;
+                const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
+                const bool stop = (pflags & kPlanStop) != 0;
+                const int jn = j0 + (do_col ? 1 : 0);
+                double rf_min = inf;
+                int rf_idx = 0x7fffffff;
+                if (do_row)
+                    otw_row_strip<W, DENSE, RT>(S, a, e, S.Dr[buf], pt, j0, jn, sentinel, rf_min, rf_idx);
+                else if (do_col && !stop)
+                    otw_col_strip<W, DENSE, RT>(S, a, e, S.Dc[buf], pt, jn, false, sentinel);
+                RTS_STAMP(3);
+                __syncthreads();
+                RTS_STAMP(5);
+                otw_control<W, DENSE, RT>(S, k, a, e, pt, j0, pflags, rf_min, rf_idx, sentinel);
+                RTS_STAMP(8);
+                __syncthreads();
+                buf ^= 1;
             }
         }
-        RTS_STAMP(3);
-        if (!stop && wave >= HW0)
-            otw_precompute<W, RT>(S, e, pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
-        RTS_STAMP(4);
-        __syncthreads();
-        RTS_STAMP(5);
+    } else {
+        // ---- step loop: one iteration = one row strip and/or one column strip + one decide()
+        for (;;) {
+            RTS_STAMP(0);
+            const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
+                      pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
+            if (pflags & kPlanExit) break;
+            const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
+            const bool stop = (pflags & kPlanStop) != 0;
+            const int jn = j0 + (do_col ? 1 : 0);
+            const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, nr = j0 - k1r + 1;  // row strip: columns
+            const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1;  // column strip: rows
+            const bool col_active = do_col && !stop;
+            double *Dr = S.Dr[buf], *Dc = S.Dc[buf];
 
-        // -- corner fix-up, decide, next plan (wave 0, register state)
-        if (wave == 0) {
-            if (!stop && e.deferred_update && k.pend_dir != -2) {  // livenote_v2.py:149-155
-                k.run_count = (k.pend_dir == k.prev) ? k.run_count + 1 : 1;
-                if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
-                k.pend_dir = -2;
+            // -- chain phase: row strip on wave 0, column strip on wave 1; spare waves pre-compute the
+            //    next step's costs meanwhile
+            const int col_wave = (NW > 1 && do_row) ? 1 : 0;
+            double rf_min = inf;
+            int rf_idx = 0x7fffffff;
+            if (do_row && wave == 0) {
+                const double x_in = (k1r > 0) ? sentinel : inf;  // (t, k1r-1) was never evaluated
+                const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // row band's lower end at decide()
+                const long long dro = ((long long)e.b * a.live_cap + pt) * N + k1r;  // cell (pt, k1r)
+                strip_chain<W, DENSE>(Dr, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx, DENSE ? a.dense_acc + dro : nullptr,
+                                      DENSE ? a.dense_cost + dro : nullptr, 1);
+                if (lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
             }
-            if (do_row) {
-                k.rows += 1;
-                k.cells += nr;
-                k.consumed = pt + 1;
+            if (col_active && wave == col_wave) {
+                const double x_in = (k1c > 0) ? sentinel : inf;  // (k1c-1, jn) was never evaluated
+                const int ncc = nc - (do_row ? 1 : 0);            // corner cell waits for the row strip
+                double fm;
+                int fi;
+                // the corner's diagonal term needs column jn-1 at row t-1, which the chain is about to overwrite
+                const double dcorner = Dc[swz<W>(pt)];
+                const double pa = (do_row && pt > 0) ? S.C[swz<W>(pt - 1)] + 2 * dcorner : inf;
+                const long long dco = ((long long)e.b * a.live_cap + k1c) * N + jn;  // cell (k1c, jn)
+                strip_chain<W, DENSE>(Dc, S.C, k1c, ncc, x_in, lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
+                                      DENSE ? a.dense_cost + dco : nullptr, N);
+                if (lane == 0) {
+                    S.corner_pa = pa;
+                    S.corner_d = dcorner;
+                    if (k1c > 0) S.C[swz<W>(k1c - 1)] = sentinel;
+                    S.cfresh_min = fm;
+                    S.cfresh_idx = fi;
+                }
             }
-            double cl = 0.0, cf_min = inf;
-            int cf_idx = 0x7fffffff;
-            // last cell of the row strip = acc[t][j0]; of the column chain = acc[t-1][jn] (Both) or acc[t][jn]
-            const double row_last = do_row ? rfl(S.R[swz<W>(j0)]) : 0.0;
-            if (do_row && !col_active && lane == 0) S.C[swz<W>(pt)] = row_last;  // column j0 gains row t
-            if (col_active) {
-                const int ncc = nc - (do_row ? 1 : 0);
-                cl = (ncc > 0) ? rfl(S.C[swz<W>(k1c + ncc - 1)]) : ((k1c > 0) ? sentinel : inf);
-                cf_min = rfl(S.cfresh_min);
-                cf_idx = __builtin_amdgcn_readfirstlane(S.cfresh_idx);
+            RTS_STAMP(3);
+            if (!stop && wave >= HW0)
+                otw_precompute<W, RT>(S, e, pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
+            RTS_STAMP(4);
+            __syncthreads();
+            RTS_STAMP(5);
+
+            // -- corner fix-up, decide, next plan (wave 0, register state)
+            if (wave == 0) {
+                if (!stop && e.deferred_update && k.pend_dir != -2) {  // livenote_v2.py:149-155
+                    k.run_count = (k.pend_dir == k.prev) ? k.run_count + 1 : 1;
+                    if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
+                    k.pend_dir = -2;
+                }
                 if (do_row) {
-                    const double d = rfl(S.corner_d);
-                    const double av = vmin(row_last + d, rfl(S.corner_pa));
-                    cl = vmin(av, cl + d);  // cl was the value of (t-1, jn), or the sentinel carry
-                    if (lane == 0) {
-                        S.C[swz<W>(pt)] = cl;
-                        if (DENSE) {
-                            const long long o = ((long long)e.b * a.live_cap + pt) * N + jn;
-                            a.dense_acc[o] = cl;
-                            a.dense_cost[o] = d;
+                    k.rows += 1;
+                    k.cells += nr;
+                    k.consumed = pt + 1;
+                }
+                double cl = 0.0, cf_min = inf;
+                int cf_idx = 0x7fffffff;
+                // last cell of the row strip = acc[t][j0]; of the column chain = acc[t-1][jn] (Both) or acc[t][jn]
+                const double row_last = do_row ? rfl(S.R[swz<W>(j0)]) : 0.0;
+                if (do_row && !col_active && lane == 0) S.C[swz<W>(pt)] = row_last;  // column j0 gains row t
+                if (col_active) {
+                    const int ncc = nc - (do_row ? 1 : 0);
+                    cl = (ncc > 0) ? rfl(S.C[swz<W>(k1c + ncc - 1)]) : ((k1c > 0) ? sentinel : inf);
+                    cf_min = rfl(S.cfresh_min);
+                    cf_idx = __builtin_amdgcn_readfirstlane(S.cfresh_idx);
+                    if (do_row) {
+                        const double d = rfl(S.corner_d);
+                        const double av = vmin(row_last + d, rfl(S.corner_pa));
+                        cl = vmin(av, cl + d);  // cl was the value of (t-1, jn), or the sentinel carry
+                        if (lane == 0) {
+                            S.C[swz<W>(pt)] = cl;
+                            if (DENSE) {
+                                const long long o = ((long long)e.b * a.live_cap + pt) * N + jn;
+                                a.dense_acc[o] = cl;
+                                a.dense_cost[o] = d;
+                            }
                         }
                     }
+                    if (lane == 0) S.R[swz<W>(jn)] = cl;  // row t gains column jn
+                    k.cols += 1;
+                    k.cells += nc;
                 }
-                if (lane == 0) S.R[swz<W>(jn)] = cl;  // row t gains column jn
-                k.cols += 1;
-                k.cells += nc;
+                RTS_STAMP(6);
+                if (stop) {
+                    k.status = RTS_STOP_REF_END;
+                    k.t = pt;
+                    k.j = jn;
+                    k.pending_col = 0;
+                } else {
+                    // row band: fresh from this step's row strip, plus the corner a column strip appended;
+                    // column band: fresh from this step's column strip (its corner cell is outside the
+                    // chain), or the old band plus the row strip's last cell
+                    otw_decide<W, RT>(S, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl,
+                                  do_row, col_active ? cl : row_last, false);
+                }
+                RTS_STAMP(7);
+                otw_make_plan<W, RT>(S, k, e);
             }
-            RTS_STAMP(6);
-            if (stop) {
-                k.status = RTS_STOP_REF_END;
-                k.t = pt;
-                k.j = jn;
-                k.pending_col = 0;
-            } else {
-                // row band: fresh from this step's row strip, plus the corner a column strip appended;
-                // column band: fresh from this step's column strip (its corner cell is outside the
-                // chain), or the old band plus the row strip's last cell
-                otw_decide<W, RT>(S, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl,
-                              do_row, col_active ? cl : row_last, false);
-            }
-            RTS_STAMP(7);
-            otw_make_plan<W, RT>(S, k, e);
+            RTS_STAMP(8);
+            __syncthreads();
+            buf ^= 1;
         }
-        RTS_STAMP(8);
-        __syncthreads();
-        buf ^= 1;
     }
     __syncthreads();
 
