@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "librtsync.so")
+# RTSYNC_LIB selects another build of the same library (A/B measurements of kernel variants in one process tree)
+SO_PATH = os.environ.get("RTSYNC_LIB") or os.path.join(_HERE, "librtsync.so")
 
 # constants mirrored from include/rtsync.h
 F32, F64 = 0, 1

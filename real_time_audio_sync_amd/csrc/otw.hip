@@ -50,6 +50,7 @@ struct OtwArgs {
     int ref_f64, live_f64;
     int clamp_len;            // run mode: never read past live_stride frames
     long long *debug;         // diagnostic builds only (-DRTS_OTW_STAMPS): [B][16] cycle sums
+    int spec;                 // speculative column strip on wave 1 (tuning knob; results identical)
     double *dense_acc;        // optional [B][2N][N]: the reference's dense acc_cost (otw_eran.py:27), NULL = off
     double *dense_cost;       // optional [B][2N][N]: the reference's dense cost (otw_eran.py:23)
 };
@@ -63,6 +64,7 @@ struct OtwLds {
     static constexpr int SWZ = L * 65;   // swizzled band length (one pad slot per row of 64)
     double R[SWZ];      // acc[t][.]  row band
     double C[SWZ];      // acc[.][j]  column band
+    double Sh[SWZ];     // shadow strip: speculative column j+1 (all rows but the corner), copied in on a hit
     double Dr[2][SWZ];  // row strip cell costs: [buf] = this step's, [buf^1] = being pre-computed for the next
     double Dc[2][SWZ];
     RT refw[kF][W];   // feature-major ring of reference frames (index y & (W-1))
@@ -72,6 +74,8 @@ struct OtwLds {
     double corner_pa;  // Both step: acc[t-1][jn-1] + 2 d(t, jn), stashed before column jn-1 is overwritten
     double corner_d;   // d(t, jn)
     int cfresh_idx;
+    double spec_min;   // argmin of the speculative strip
+    int spec_idx;
     int plan_t, plan_j0, plan_flags;  // wave 0 -> everyone: the next step
     int t, j;                         // final position, published at exit for the epilogue
 };
@@ -186,7 +190,8 @@ __device__ __forceinline__ double wave_min(double x) {
 //                                                        (band = previous row for a row strip,
 //                                                        previous column for a column strip)
 //     acc_i = min(a_i, acc_{i-1} + d_i),  acc_{-1} = x_in the predecessor inside the strip
-// and `band` is overwritten in place with acc (the wave reads all old values before it writes).
+// and the new strip goes to `band_out` -- `band` itself for a regular strip (in place: the wave reads all
+// old values before it writes), the shadow strip for a speculative one.
 // Returns np.argmin (first minimum) of the new strip restricted to band positions >= lo_arg:
 // (fmin, fidx), fidx = 0x7fffffff if that range is empty.  The caller reads acc_{n-1} back from
 // band[swz(k1+n-1)].
@@ -202,8 +207,8 @@ __device__ __forceinline__ double wave_min(double x) {
 // before it is ever read (rows/columns only grow at the top index).  Valid cells are always finite:
 // each has a computed predecessor in the previous row (row strip) or column (column strip).
 template <int W, bool DENSE>
-__device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, double *__restrict__ band, int k1, int n,
-                                            double x_in, int lane, int lo_arg, double &fmin_out, int &fidx_out,
+__device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const double *band, double *band_out, int k1,
+                                            int n, double x_in, int lane, int lo_arg, double &fmin_out, int &fidx_out,
                                             double *dense_acc, double *dense_cost, long long dense_stride) {
     constexpr int L = W / 64;
     constexpr int LOG_L = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : 3;
@@ -253,7 +258,7 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, doubl
         }
     }
 #pragma unroll
-    for (int m = 0; m < L; m++) band[slot[m + 1]] = v[m];
+    for (int m = 0; m < L; m++) band_out[slot[m + 1]] = v[m];
     if (DENSE) {  // optional: mirror the strip into the reference's dense matrices (cell i at base + i*stride)
 #pragma unroll
         for (int m = 0; m < L; m++) {
@@ -329,6 +334,7 @@ struct OtwCtl {
     int t, j, dir, prev, run_count, status, first, n_path, consumed, rows, cols, truncated, pend_dir;
     int recomputes, pending_col, last_x, last_y, rb_idx, cb_idx;
     int live_hi, ref_hi;  // highest frame index present in the live / reference ring
+    int spec_t, spec_j;   // wave 1 holds a speculative column strip for column spec_j at rows < spec_t (spec_j < 0: none)
     long long cells;
     double rb_min, cb_min;          // np.argmin state of the two bands at the last decide()
     double pfl0, pfl1, pfr0, pfr1;  // prefetched ring frames (two values per lane of wave 0)
@@ -342,7 +348,7 @@ struct OtwEnv {  // launch-invariant values every helper needs
     bool deferred_update;
 };
 
-constexpr int kPlanRow = 1, kPlanCol = 2, kPlanStop = 4, kPlanExit = 8;
+constexpr int kPlanRow = 1, kPlanCol = 2, kPlanStop = 4, kPlanExit = 8, kPlanHit = 16;
 
 __device__ __forceinline__ double otw_load_feat(const void *base, int is_f64, long long idx) {
     return is_f64 ? reinterpret_cast<const double *>(base)[idx] : (double)reinterpret_cast<const float *>(base)[idx];
@@ -541,6 +547,8 @@ __device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const
         flags = kPlanRow | ((k.dir != RTS_DIR_ROW) ? kPlanCol : 0);
     }
     if ((flags & kPlanCol) && k.j + 1 >= e.N) flags |= kPlanStop;  // otw_eran.py:67-71
+    // is the Column-only step about to run exactly the strip wave 1 computed on the side last step?
+    if (flags == kPlanCol && k.spec_j == k.j + 1 && k.spec_t == pt) flags |= kPlanHit;
     if (e.lane == 0) {
         S.plan_t = pt;
         S.plan_j0 = k.j;
@@ -570,8 +578,8 @@ __device__ __forceinline__ void otw_row_strip(OtwLds<W, RT> &S, const OtwArgs &a
     const double x_in = (k1r > 0) ? sentinel : (double)INFINITY;  // (t, k1r-1) was never evaluated
     const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;        // row band's lower end at decide()
     const long long dro = ((long long)e.b * e.live_cap + pt) * e.N + k1r;  // cell (pt, k1r)
-    strip_chain<W, DENSE>(Dr, S.R, k1r, nr, x_in, e.lane, lo_arg, rf_min, rf_idx, DENSE ? a.dense_acc + dro : nullptr,
-                          DENSE ? a.dense_cost + dro : nullptr, 1);
+    strip_chain<W, DENSE>(Dr, S.R, S.R, k1r, nr, x_in, e.lane, lo_arg, rf_min, rf_idx,
+                          DENSE ? a.dense_acc + dro : nullptr, DENSE ? a.dense_cost + dro : nullptr, 1);
     if (e.lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
 }
 
@@ -589,7 +597,7 @@ __device__ __forceinline__ void otw_col_strip(OtwLds<W, RT> &S, const OtwArgs &a
     const double dcorner = Dc[swz<W>(pt)];
     const double pa = (with_row && pt > 0) ? S.C[swz<W>(pt - 1)] + 2 * dcorner : (double)INFINITY;
     const long long dco = ((long long)e.b * e.live_cap + k1c) * e.N + jn;  // cell (k1c, jn)
-    strip_chain<W, DENSE>(Dc, S.C, k1c, ncc, x_in, e.lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
+    strip_chain<W, DENSE>(Dc, S.C, S.C, k1c, ncc, x_in, e.lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
                           DENSE ? a.dense_cost + dco : nullptr, e.N);
     if (e.lane == 0) {
         S.corner_pa = pa;
@@ -600,10 +608,65 @@ __device__ __forceinline__ void otw_col_strip(OtwLds<W, RT> &S, const OtwArgs &a
     }
 }
 
+// Speculative column strip (wave 1, during a Row-only step): column j0+1 over rows [k1c, pt-1] -- every cell but
+// the corner, exactly like the column strip of a Both step -- from the intact column band into the shadow strip.
+template <int W, typename RT>
+__device__ __forceinline__ void otw_spec_col_strip(OtwLds<W, RT> &S, const OtwEnv &e, const double *Dc, int pt,
+                                                   double sentinel) {
+    const int c = e.c;
+    const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1;
+    double fm;
+    int fi;
+    strip_chain<W, false>(Dc, S.C, S.Sh, k1c, nc - 1, (k1c > 0) ? sentinel : (double)INFINITY, e.lane, k1c, fm, fi,
+                          nullptr, nullptr, 0);
+    if (e.lane == 0) {
+        S.spec_min = fm;
+        S.spec_idx = fi;
+    }
+}
+
+// Control phase of a *hit* step (wave 0): this Column-only step's strip, column jn = j0+1 over rows [k1c, pt-1],
+// was computed by wave 1 during the previous step and sits in the shadow strip.  Take what the corner (pt, jn)
+// needs from column jn-1, copy the shadow over the column band (every ring slot: the slots outside the strip hold
+// +inf and are rewritten here or before any read), finish the corner, decide, plan.
+template <int W, typename RT>
+__device__ __forceinline__ void otw_control_hit(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, int pt, int j0,
+                                                const double *Dc, double sentinel) {
+    const int c = e.c, lane = e.lane;
+    const double inf = INFINITY;
+    const int jn = j0 + 1;
+    const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1, ncc = nc - 1;
+    if (e.deferred_update && k.pend_dir != -2) {  // livenote_v2.py:149-155
+        k.run_count = (k.pend_dir == k.prev) ? k.run_count + 1 : 1;
+        if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
+        k.pend_dir = -2;
+    }
+    const double d = rfl(Dc[swz<W>(pt)]);
+    const double pa = (pt > 0) ? rfl(S.C[swz<W>(pt - 1)]) + 2 * d : inf;
+    const double left = rfl(S.C[swz<W>(pt)]) + d;
+    const double up_prev = (ncc > 0) ? rfl(S.Sh[swz<W>(k1c + ncc - 1)]) : ((k1c > 0) ? sentinel : inf);
+    for (int sidx = lane; sidx < OtwLds<W, RT>::SWZ; sidx += 64) S.C[sidx] = S.Sh[sidx];
+    const double cl = vmin(vmin(left, pa), up_prev + d);
+    if (lane == 0) {
+        S.C[swz<W>(pt)] = cl;
+        if (k1c > 0) S.C[swz<W>(k1c - 1)] = sentinel;
+        S.R[swz<W>(jn)] = cl;  // row t gains column jn
+    }
+    k.cols += 1;
+    k.cells += nc;
+    k.spec_j = -1;
+    k.spec_t = pt;
+    // column band: the speculative strip's argmin plus the corner; row band: the kept minimum plus the corner
+    otw_decide<W, RT>(S, k, e, pt, jn, false, inf, 0x7fffffff, true, rfl(S.spec_min),
+                      __builtin_amdgcn_readfirstlane(S.spec_idx), true, cl, true, cl, false);
+    otw_make_plan<W, RT>(S, k, e);
+}
+
 // Control phase of one step (wave 0): corner fix-up, decide(), next plan.
 template <int W, bool DENSE, typename RT>
 __device__ __forceinline__ void otw_control(OtwLds<W, RT> &S, OtwCtl &k, const OtwArgs &a, const OtwEnv &e,
-                                            int pt, int j0, int pflags, double rf_min, int rf_idx, double sentinel) {
+                                            int pt, int j0, int pflags, double rf_min, int rf_idx, double sentinel,
+                                            bool spec_launched) {
     const int c = e.c, lane = e.lane;
     const double inf = INFINITY;
     const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
@@ -649,6 +712,8 @@ __device__ __forceinline__ void otw_control(OtwLds<W, RT> &S, OtwCtl &k, const O
         k.cols += 1;
         k.cells += nc;
     }
+    k.spec_j = spec_launched ? j0 + 1 : -1;  // what wave 1 computed on the side, if anything
+    k.spec_t = pt;
     if (stop) {
         k.status = RTS_STOP_REF_END;
         k.t = pt;
@@ -657,7 +722,7 @@ __device__ __forceinline__ void otw_control(OtwLds<W, RT> &S, OtwCtl &k, const O
     } else {
         // row band: fresh from this step's row strip, plus the corner a column strip appended;
         // column band: fresh from this step's column strip (its corner cell is outside the
-        // chain), or the old band plus the row strip's last cell
+        // chain: Both step, or a speculative strip), or the old band plus the row strip's last cell
         otw_decide<W, RT>(S, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl, do_row,
                           col_active ? cl : row_last, false);
     }
@@ -741,6 +806,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     k.rb_idx = 0;
     k.cb_idx = 0;
     k.pfl0 = k.pfl1 = k.pfr0 = k.pfr1 = 0.0;
+    k.spec_t = -1;
+    k.spec_j = -1;
 
     if (k.status == RTS_STOP_REF_END) return;  // sticky; the reference's callers stop inserting
     if (k.status == RTS_LIVE_OVERFLOW) {       // otw_eran.py:50-55: t keeps counting inserts
@@ -756,6 +823,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     for (int i = tid; i < OtwLds<W, RT>::SWZ; i += NT) {  // no uninitialised LDS ever reaches the arithmetic
         S.R[i] = 0.0;
         S.C[i] = 0.0;
+        S.Sh[i] = 0.0;
         S.Dr[0][i] = S.Dr[1][i] = S.Dc[0][i] = S.Dc[1][i] = 0.0;
     }
     __syncthreads();
@@ -846,6 +914,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         // a step (a step = one row strip and/or one column strip + one decide()), so each loop keeps only its own
         // values live: helpers pre-compute costs, wave 1 runs the column strip of Both steps, wave 0 runs the
         // (other) strip and then the control phase.  All of them read the plan wave 0 published.
+        constexpr bool kSpec = !DENSE;  // the dense mirror must only ever see real strips
         if (wave >= HW0) {
             for (;;) {
                 const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
@@ -854,8 +923,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 const int jn = j0 + ((pflags & kPlanCol) ? 1 : 0);
                 if (!(pflags & kPlanStop))
                     otw_precompute<W, RT>(S, e, pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
-                __syncthreads();  // strips and next costs complete
-                __syncthreads();  // next plan published
+                if (!(pflags & kPlanHit)) __syncthreads();  // strips complete (a hit step has none)
+                __syncthreads();                            // next costs complete, next plan published
                 buf ^= 1;
             }
         } else if (wave == 1) {
@@ -863,9 +932,15 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
                           pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
                 if (pflags & kPlanExit) break;
-                if ((pflags & (kPlanRow | kPlanCol | kPlanStop)) == (kPlanRow | kPlanCol))  // Both step
+                const int kind = pflags & (kPlanRow | kPlanCol | kPlanStop);
+                if (kind == (kPlanRow | kPlanCol)) {  // Both step: the column strip
                     otw_col_strip<W, DENSE, RT>(S, a, e, S.Dc[buf], pt, j0 + 1, true, sentinel);
-                __syncthreads();
+                } else if (kSpec && a.spec && kind == kPlanRow && j0 + 1 < N) {
+                    // Row-only step: run the column strip the next step needs if decide() says "Column"
+                    // (~70 % in steady state); its costs are already in Dc
+                    otw_spec_col_strip<W, RT>(S, e, S.Dc[buf], pt, sentinel);
+                }
+                if (!(pflags & kPlanHit)) __syncthreads();
                 __syncthreads();
                 buf ^= 1;
             }
@@ -875,6 +950,12 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
                           pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
                 if (pflags & kPlanExit) break;
+                if (kSpec && (pflags & kPlanHit)) {  // a step whose strip already exists: control only, one barrier
+                    otw_control_hit<W, RT>(S, k, e, pt, j0, S.Dc[buf], sentinel);
+                    __syncthreads();
+                    buf ^= 1;
+                    continue;
+                }
                 const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
                 const bool stop = (pflags & kPlanStop) != 0;
                 const int jn = j0 + (do_col ? 1 : 0);
@@ -887,7 +968,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 RTS_STAMP(3);
                 __syncthreads();
                 RTS_STAMP(5);
-                otw_control<W, DENSE, RT>(S, k, a, e, pt, j0, pflags, rf_min, rf_idx, sentinel);
+                const bool spec_launched = kSpec && a.spec && do_row && !do_col && (j0 + 1 < N);
+                otw_control<W, DENSE, RT>(S, k, a, e, pt, j0, pflags, rf_min, rf_idx, sentinel, spec_launched);
                 RTS_STAMP(8);
                 __syncthreads();
                 buf ^= 1;
@@ -917,8 +999,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 const double x_in = (k1r > 0) ? sentinel : inf;  // (t, k1r-1) was never evaluated
                 const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // row band's lower end at decide()
                 const long long dro = ((long long)e.b * a.live_cap + pt) * N + k1r;  // cell (pt, k1r)
-                strip_chain<W, DENSE>(Dr, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx, DENSE ? a.dense_acc + dro : nullptr,
-                                      DENSE ? a.dense_cost + dro : nullptr, 1);
+                strip_chain<W, DENSE>(Dr, S.R, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx,
+                                      DENSE ? a.dense_acc + dro : nullptr, DENSE ? a.dense_cost + dro : nullptr, 1);
                 if (lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
             }
             if (col_active && wave == col_wave) {
@@ -930,7 +1012,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 const double dcorner = Dc[swz<W>(pt)];
                 const double pa = (do_row && pt > 0) ? S.C[swz<W>(pt - 1)] + 2 * dcorner : inf;
                 const long long dco = ((long long)e.b * a.live_cap + k1c) * N + jn;  // cell (k1c, jn)
-                strip_chain<W, DENSE>(Dc, S.C, k1c, ncc, x_in, lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
+                strip_chain<W, DENSE>(Dc, S.C, S.C, k1c, ncc, x_in, lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
                                       DENSE ? a.dense_cost + dco : nullptr, N);
                 if (lane == 0) {
                     S.corner_pa = pa;
@@ -1122,6 +1204,7 @@ struct rts_otw {
     int32_t *hist_len;  // [B]
     long long *debug;   // diagnostic builds only
     double *dense_acc, *dense_cost;  // caller-owned, optional
+    int spec;
 };
 
 namespace rts {
@@ -1186,6 +1269,7 @@ static OtwArgs base_args(const rts_otw *h) {
     a.live_cap = h->live_cap;
     a.ref_f64 = h->ref_dtype == RTS_F64;
     a.debug = h->debug;
+    a.spec = h->spec;
     a.dense_acc = h->dense_acc;
     a.dense_cost = h->dense_cost;
     return a;
@@ -1228,6 +1312,10 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     h->W = 64;
     while (h->W < c + 12) h->W *= 2;
     h->waves = 8;  // waves 0/1 run the chains, 2..7 pre-compute the next step's costs
+    {
+        const char *sp = getenv("RTS_OTW_SPEC");
+        h->spec = sp ? atoi(sp) : 1;
+    }
     h->live_cap = 2 * N;
     h->path_cap = 3 * N + 8;  // one point per decide(); decides <= row strips + column strips <= 2N + N
     hipError_t e;
