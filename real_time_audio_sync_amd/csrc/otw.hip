@@ -50,7 +50,7 @@ struct OtwArgs {
     int ref_f64, live_f64;
     int clamp_len;            // run mode: never read past live_stride frames
     long long *debug;         // diagnostic builds only (-DRTS_OTW_STAMPS): [B][16] cycle sums
-    int spec;                 // speculative column strip on wave 1 (tuning knob; results identical)
+    int spec;                 // informational: 1 when the pipelined (speculating) kernel was selected
     double *dense_acc;        // optional [B][2N][N]: the reference's dense acc_cost (otw_eran.py:27), NULL = off
     double *dense_cost;       // optional [B][2N][N]: the reference's dense cost (otw_eran.py:23)
 };
@@ -64,7 +64,6 @@ struct OtwLds {
     static constexpr int SWZ = L * 65;   // swizzled band length (one pad slot per row of 64)
     double R[SWZ];      // acc[t][.]  row band
     double C[SWZ];      // acc[.][j]  column band
-    double Sh[SWZ];     // shadow strip: speculative column j+1 (all rows but the corner), copied in on a hit
     double Dr[2][SWZ];  // row strip cell costs: [buf] = this step's, [buf^1] = being pre-computed for the next
     double Dc[2][SWZ];
     RT refw[kF][W];   // feature-major ring of reference frames (index y & (W-1))
@@ -74,10 +73,28 @@ struct OtwLds {
     double corner_pa;  // Both step: acc[t-1][jn-1] + 2 d(t, jn), stashed before column jn-1 is overwritten
     double corner_d;   // d(t, jn)
     int cfresh_idx;
-    double spec_min;   // argmin of the speculative strip
-    int spec_idx;
-    int plan_t, plan_j0, plan_flags;  // wave 0 -> everyone: the next step
+    // wave 0 -> everyone: the next step.  The pipelined kernel alternates between the two slots, because its hit
+    // steps have no barrier between the other waves' read of a plan and wave 0's write of the next one.
+    int plan_t[2], plan_j0[2], plan_flags[2];
     int t, j;                         // final position, published at exit for the epilogue
+};
+
+// Extra LDS of the pipelined kernel (SPEC).  The row band lives in R or ShR and the column band in C or ShC
+// (the plan says which); the other buffer of each pair is the *shadow* the speculating wave fills with the strip the
+// next Row-only / Column-only step needs, minus its last cell.  When that step comes, the shadow simply becomes the
+// band.  ex[] (indexed by step parity) is what the speculating waves hand to wave 0 along with a shadow.
+struct OtwSpecOut {
+    double min;  // np.argmin of the shadow strip
+    double d;    // cost of the strip's last cell (the one the shadow leaves out)
+    int idx;
+    int pad;
+};
+template <int W>
+struct alignas(16) OtwSpecLds {
+    static constexpr int SWZ = (W / 64) * 65;
+    double ShR[SWZ];
+    double ShC[SWZ];
+    OtwSpecOut row[2], col[2];
 };
 
 // Band position -> LDS slot.  Cell k lives at row (k mod L), column (k / L mod 64): the chain
@@ -190,8 +207,10 @@ __device__ __forceinline__ double wave_min(double x) {
 //                                                        (band = previous row for a row strip,
 //                                                        previous column for a column strip)
 //     acc_i = min(a_i, acc_{i-1} + d_i),  acc_{-1} = x_in the predecessor inside the strip
-// and the new strip goes to `band_out` -- `band` itself for a regular strip (in place: the wave reads all
-// old values before it writes), the shadow strip for a speculative one.
+// and the new strip goes to `band_out`: `band` itself for a regular strip (in place -- the wave reads all old
+// values before it writes), a shadow strip for a speculative one.  GUARD (speculative strips, which run while
+// wave 0 is writing the corner slots just past the strip's inputs): lanes whose cells lie past the strip end
+// read band position k1-1 instead of their own slots, so no slot that is being written is ever read.
 // Returns np.argmin (first minimum) of the new strip restricted to band positions >= lo_arg:
 // (fmin, fidx), fidx = 0x7fffffff if that range is empty.  The caller reads acc_{n-1} back from
 // band[swz(k1+n-1)].
@@ -206,7 +225,7 @@ __device__ __forceinline__ double wave_min(double x) {
 // corner slot, which the fix-up rewrites; every band position is written with its real value
 // before it is ever read (rows/columns only grow at the top index).  Valid cells are always finite:
 // each has a computed predecessor in the previous row (row strip) or column (column strip).
-template <int W, bool DENSE>
+template <int W, bool DENSE, bool GUARD = false>
 __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const double *band, double *band_out, int k1,
                                             int n, double x_in, int lane, int lo_arg, double &fmin_out, int &fidx_out,
                                             double *dense_acc, double *dense_cost, long long dense_stride) {
@@ -224,7 +243,15 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
     const int nloc = n - L * lane;  // cell m of this lane is inside the strip iff m < nloc
     double prevb[L + 1], D[L], v[L];
 #pragma unroll
-    for (int m = 0; m <= L; m++) prevb[m] = band[slot[m]];  // positions k-1 .. k+L-1
+    for (int m = 0; m <= L; m++) {  // positions k-1 .. k+L-1
+        if (GUARD) {
+            const int q0 = k1 - 1 + W;
+            const int safe = (q0 & (L - 1)) * 65 + ((q0 >> LOG_L) & 63);
+            prevb[m] = band[(m <= nloc) ? slot[m] : safe];  // position index L*lane + m - 1 <= n - 1
+        } else {
+            prevb[m] = band[slot[m]];
+        }
+    }
 #pragma unroll
     for (int m = 0; m < L; m++) D[m] = Dv[slot[m + 1]];
     prevb[0] = (k1 == 0 && lane == 0) ? inf : prevb[0];  // row/column 0 has no diagonal predecessor
@@ -259,6 +286,11 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
     }
 #pragma unroll
     for (int m = 0; m < L; m++) band_out[slot[m + 1]] = v[m];
+    // a shadow strip is installed as it is: position k1-1 (= k1+W-1 on the ring, lane 63's last cell, always
+    // past the strip end) gets the value an in-place strip's caller writes there afterwards
+    if (GUARD) {
+        if (lane == 63) band_out[slot[L]] = x_in;
+    }
     if (DENSE) {  // optional: mirror the strip into the reference's dense matrices (cell i at base + i*stride)
 #pragma unroll
         for (int m = 0; m < L; m++) {
@@ -313,8 +345,16 @@ __device__ __forceinline__ void band_argmin(const double *__restrict__ band, int
 }
 
 // In-kernel cycle stamps exist only in the diagnostic build (tools/otw_phase_profile.py); the
-// shipped library compiles them away.
-#ifdef RTS_OTW_STAMPS
+// shipped library compiles them away.  -DRTS_OTW_STAMPS=1: per-phase stamps (they inflate what they measure);
+// -DRTS_OTW_STAMPS=2: only wave 0's work / end-of-step wait split of the pipelined kernel, two stamps per step.
+#if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 1
+#define RTS_STAMP2(slot)      \
+    do {                      \
+        if (stamp_base)       \
+            RTS_STAMP(8 + slot); \
+        else                  \
+            RTS_STAMP(slot);  \
+    } while (0)
 #define RTS_STAMP(slot)                                                   \
     do {                                                                  \
         const long long now_ = (long long)__builtin_amdgcn_s_memtime();   \
@@ -326,6 +366,9 @@ __device__ __forceinline__ void band_argmin(const double *__restrict__ band, int
 #define RTS_STAMP(slot) \
     do {                \
     } while (0)
+#define RTS_STAMP2(slot) \
+    do {                 \
+    } while (0)
 #endif
 
 // ---- control state of one stream.  Lives in wave 0's registers (every lane identical) for the whole
@@ -334,7 +377,10 @@ struct OtwCtl {
     int t, j, dir, prev, run_count, status, first, n_path, consumed, rows, cols, truncated, pend_dir;
     int recomputes, pending_col, last_x, last_y, rb_idx, cb_idx;
     int live_hi, ref_hi;  // highest frame index present in the live / reference ring
-    int spec_t, spec_j;   // wave 1 holds a speculative column strip for column spec_j at rows < spec_t (spec_j < 0: none)
+    int spec_valid;       // pipelined kernel: the shadow strips were computed from the current (t, j)
+    int ri, ci;           // pipelined kernel: which buffer of each pair holds the row / column band
+    double cA, cU, cL;    // pipelined kernel: band slots acc[t][j], column slot t-1, row slot j-1 (hit steps
+                          // finish their last cell from these without touching the old band)
     long long cells;
     double rb_min, cb_min;          // np.argmin state of the two bands at the last decide()
     double pfl0, pfl1, pfr0, pfr1;  // prefetched ring frames (two values per lane of wave 0)
@@ -348,7 +394,9 @@ struct OtwEnv {  // launch-invariant values every helper needs
     bool deferred_update;
 };
 
-constexpr int kPlanRow = 1, kPlanCol = 2, kPlanStop = 4, kPlanExit = 8, kPlanHit = 16;
+constexpr int kPlanRow = 1, kPlanCol = 2, kPlanStop = 4, kPlanExit = 8;
+constexpr int kPlanHit = 16;  // pipelined kernel: this Row-only / Column-only step's strip already sits in its shadow
+constexpr int kPlanRi = 32, kPlanCi = 64;  // pipelined kernel: buffer holding the row / column band in this step
 
 __device__ __forceinline__ double otw_load_feat(const void *base, int is_f64, long long idx) {
     return is_f64 ? reinterpret_cast<const double *>(base)[idx] : (double)reinterpret_cast<const float *>(base)[idx];
@@ -435,9 +483,9 @@ __device__ __forceinline__ void otw_precompute(OtwLds<W, RT> &S, const OtwEnv &e
 // unless that cell left the window (then a full wave reduction recomputes it); the one cell
 // appended at the top index wins only if strictly smaller (np.argmin returns the first minimum).
 template <int W, typename RT>
-__device__ __forceinline__ void otw_decide(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, int tt, int jj, bool row_fresh,
-                                           double rf_min, int rf_idx, bool col_fresh, double cf_min, int cf_idx,
-                                           bool row_corner, double rc, bool col_corner, double cc, bool full) {
+__device__ __forceinline__ void otw_decide(const double *R, const double *C, OtwCtl &k, const OtwEnv &e, int tt, int jj,
+                                           bool row_fresh, double rf_min, int rf_idx, bool col_fresh, double cf_min,
+                                           int cf_idx, bool row_corner, double rc, bool col_corner, double cc, bool full) {
     const int c = e.c;
     const int j1 = (jj - c + 1 > 0) ? jj - c + 1 : 0;
     const int t1 = (tt - c + 1 > 0) ? tt - c + 1 : 0;
@@ -449,7 +497,7 @@ __device__ __forceinline__ void otw_decide(OtwLds<W, RT> &S, OtwCtl &k, const Ot
     if (need_r || need_c) {
         for (int which = 0; which < 2; which++) {  // a single inlined instance of the wave reduction
             if (!(which ? need_c : need_r)) continue;
-            const double *band = which ? S.C : S.R;
+            const double *band = which ? C : R;
             const int lo = which ? t1 : j1;
             const int hi = which ? ((col_corner && !full) ? tt - 1 : tt) : ((row_corner && !full) ? jj - 1 : jj);
             double vm;
@@ -528,7 +576,8 @@ __device__ __forceinline__ void otw_decide(OtwLds<W, RT> &S, OtwCtl &k, const Ot
 
 // Plan for the next step from the current register state (wave 0); lane 0 publishes it.
 template <int W, typename RT>
-__device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e) {
+__device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, bool spec = false,
+                                              int slot = 0) {
     int flags = 0, pt = k.t;
     if (k.status != RTS_RUNNING) {
         flags = kPlanExit;
@@ -547,12 +596,20 @@ __device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const
         flags = kPlanRow | ((k.dir != RTS_DIR_ROW) ? kPlanCol : 0);
     }
     if ((flags & kPlanCol) && k.j + 1 >= e.N) flags |= kPlanStop;  // otw_eran.py:67-71
-    // is the Column-only step about to run exactly the strip wave 1 computed on the side last step?
-    if (flags == kPlanCol && k.spec_j == k.j + 1 && k.spec_t == pt) flags |= kPlanHit;
+    if (spec) {
+        if (k.spec_valid && (flags == kPlanRow || flags == kPlanCol)) {  // the shadow becomes the band
+            flags |= kPlanHit;
+            if (flags & kPlanRow)
+                k.ri ^= 1;
+            else
+                k.ci ^= 1;
+        }
+        flags |= (k.ri ? kPlanRi : 0) | (k.ci ? kPlanCi : 0);
+    }
     if (e.lane == 0) {
-        S.plan_t = pt;
-        S.plan_j0 = k.j;
-        S.plan_flags = flags;
+        S.plan_t[slot] = pt;
+        S.plan_j0[slot] = k.j;
+        S.plan_flags[slot] = flags;
         if (flags & kPlanExit) {
             S.t = k.t;
             S.j = k.j;
@@ -561,8 +618,9 @@ __device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const
     // keep the rings one frame ahead of what this step's cost pre-computation will read
     if (!(flags & kPlanExit)) {
         const int jn_p = k.j + ((flags & kPlanCol) ? 1 : 0);
-        const int need_l = (pt + 1 < e.live_len - 1) ? pt + 1 : e.live_len - 1;
-        const int need_r = (jn_p + 1 < e.N - 1) ? jn_p + 1 : e.N - 1;
+        const int ahead = spec ? 2 : 1;  // the pipelined kernel's helpers work one row / column further out
+        const int need_l = (pt + ahead < e.live_len - 1) ? pt + ahead : e.live_len - 1;
+        const int need_r = (jn_p + ahead < e.N - 1) ? jn_p + ahead : e.N - 1;
         if (need_l > k.live_hi) otw_commit_live<W, RT>(S, k, e);
         if (need_r > k.ref_hi) otw_commit_ref<W, RT>(S, k, e);
     }
@@ -571,23 +629,23 @@ __device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const
 // This step's row strip (t, [k1r, j0]) on the calling wave; returns its argmin restricted to the row
 // band decide() will look at.
 template <int W, bool DENSE, typename RT>
-__device__ __forceinline__ void otw_row_strip(OtwLds<W, RT> &S, const OtwArgs &a, const OtwEnv &e, const double *Dr,
+__device__ __forceinline__ void otw_row_strip(double *R, const OtwArgs &a, const OtwEnv &e, const double *Dr,
                                               int pt, int j0, int jn, double sentinel, double &rf_min, int &rf_idx) {
     const int c = e.c;
     const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, nr = j0 - k1r + 1;
     const double x_in = (k1r > 0) ? sentinel : (double)INFINITY;  // (t, k1r-1) was never evaluated
     const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;        // row band's lower end at decide()
     const long long dro = ((long long)e.b * e.live_cap + pt) * e.N + k1r;  // cell (pt, k1r)
-    strip_chain<W, DENSE>(Dr, S.R, S.R, k1r, nr, x_in, e.lane, lo_arg, rf_min, rf_idx,
-                          DENSE ? a.dense_acc + dro : nullptr, DENSE ? a.dense_cost + dro : nullptr, 1);
-    if (e.lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
+    strip_chain<W, DENSE>(Dr, R, R, k1r, nr, x_in, e.lane, lo_arg, rf_min, rf_idx, DENSE ? a.dense_acc + dro : nullptr,
+                          DENSE ? a.dense_cost + dro : nullptr, 1);
+    if (e.lane == 0 && k1r > 0) R[swz<W>(k1r - 1)] = sentinel;
 }
 
 // This step's column strip ([k1c, pt or pt-1], jn) on the calling wave; in a Both step (with_row) the corner
 // cell (pt, jn) is left to the fix-up and its diagonal term is stashed before column jn-1 is overwritten.
 template <int W, bool DENSE, typename RT>
-__device__ __forceinline__ void otw_col_strip(OtwLds<W, RT> &S, const OtwArgs &a, const OtwEnv &e, const double *Dc,
-                                              int pt, int jn, bool with_row, double sentinel) {
+__device__ __forceinline__ void otw_col_strip(OtwLds<W, RT> &S, double *C, const OtwArgs &a, const OtwEnv &e,
+                                              const double *Dc, int pt, int jn, bool with_row, double sentinel) {
     const int c = e.c;
     const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1;
     const double x_in = (k1c > 0) ? sentinel : (double)INFINITY;  // (k1c-1, jn) was never evaluated
@@ -595,78 +653,31 @@ __device__ __forceinline__ void otw_col_strip(OtwLds<W, RT> &S, const OtwArgs &a
     double fm;
     int fi;
     const double dcorner = Dc[swz<W>(pt)];
-    const double pa = (with_row && pt > 0) ? S.C[swz<W>(pt - 1)] + 2 * dcorner : (double)INFINITY;
+    const double pa = (with_row && pt > 0) ? C[swz<W>(pt - 1)] + 2 * dcorner : (double)INFINITY;
     const long long dco = ((long long)e.b * e.live_cap + k1c) * e.N + jn;  // cell (k1c, jn)
-    strip_chain<W, DENSE>(Dc, S.C, S.C, k1c, ncc, x_in, e.lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
+    strip_chain<W, DENSE>(Dc, C, C, k1c, ncc, x_in, e.lane, k1c, fm, fi, DENSE ? a.dense_acc + dco : nullptr,
                           DENSE ? a.dense_cost + dco : nullptr, e.N);
     if (e.lane == 0) {
         S.corner_pa = pa;
         S.corner_d = dcorner;
-        if (k1c > 0) S.C[swz<W>(k1c - 1)] = sentinel;
+        if (k1c > 0) C[swz<W>(k1c - 1)] = sentinel;
         S.cfresh_min = fm;
         S.cfresh_idx = fi;
     }
 }
 
-// Speculative column strip (wave 1, during a Row-only step): column j0+1 over rows [k1c, pt-1] -- every cell but
-// the corner, exactly like the column strip of a Both step -- from the intact column band into the shadow strip.
-template <int W, typename RT>
-__device__ __forceinline__ void otw_spec_col_strip(OtwLds<W, RT> &S, const OtwEnv &e, const double *Dc, int pt,
-                                                   double sentinel) {
-    const int c = e.c;
-    const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1;
-    double fm;
-    int fi;
-    strip_chain<W, false>(Dc, S.C, S.Sh, k1c, nc - 1, (k1c > 0) ? sentinel : (double)INFINITY, e.lane, k1c, fm, fi,
-                          nullptr, nullptr, 0);
-    if (e.lane == 0) {
-        S.spec_min = fm;
-        S.spec_idx = fi;
-    }
-}
+// What decide() needs to know about the step that just ran.
+struct OtwSettled {
+    bool row_fresh, col_fresh, row_corner, col_corner, stop;
+    double rf_min, cf_min, rc, cc;
+    int rf_idx, cf_idx;
+};
 
-// Control phase of a *hit* step (wave 0): this Column-only step's strip, column jn = j0+1 over rows [k1c, pt-1],
-// was computed by wave 1 during the previous step and sits in the shadow strip.  Take what the corner (pt, jn)
-// needs from column jn-1, copy the shadow over the column band (every ring slot: the slots outside the strip hold
-// +inf and are rewritten here or before any read), finish the corner, decide, plan.
-template <int W, typename RT>
-__device__ __forceinline__ void otw_control_hit(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, int pt, int j0,
-                                                const double *Dc, double sentinel) {
-    const int c = e.c, lane = e.lane;
-    const double inf = INFINITY;
-    const int jn = j0 + 1;
-    const int k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0, nc = pt - k1c + 1, ncc = nc - 1;
-    if (e.deferred_update && k.pend_dir != -2) {  // livenote_v2.py:149-155
-        k.run_count = (k.pend_dir == k.prev) ? k.run_count + 1 : 1;
-        if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
-        k.pend_dir = -2;
-    }
-    const double d = rfl(Dc[swz<W>(pt)]);
-    const double pa = (pt > 0) ? rfl(S.C[swz<W>(pt - 1)]) + 2 * d : inf;
-    const double left = rfl(S.C[swz<W>(pt)]) + d;
-    const double up_prev = (ncc > 0) ? rfl(S.Sh[swz<W>(k1c + ncc - 1)]) : ((k1c > 0) ? sentinel : inf);
-    for (int sidx = lane; sidx < OtwLds<W, RT>::SWZ; sidx += 64) S.C[sidx] = S.Sh[sidx];
-    const double cl = vmin(vmin(left, pa), up_prev + d);
-    if (lane == 0) {
-        S.C[swz<W>(pt)] = cl;
-        if (k1c > 0) S.C[swz<W>(k1c - 1)] = sentinel;
-        S.R[swz<W>(jn)] = cl;  // row t gains column jn
-    }
-    k.cols += 1;
-    k.cells += nc;
-    k.spec_j = -1;
-    k.spec_t = pt;
-    // column band: the speculative strip's argmin plus the corner; row band: the kept minimum plus the corner
-    otw_decide<W, RT>(S, k, e, pt, jn, false, inf, 0x7fffffff, true, rfl(S.spec_min),
-                      __builtin_amdgcn_readfirstlane(S.spec_idx), true, cl, true, cl, false);
-    otw_make_plan<W, RT>(S, k, e);
-}
-
-// Control phase of one step (wave 0): corner fix-up, decide(), next plan.
+// First half of the control phase of a regular step (wave 0): counters and the corner fix-up.
 template <int W, bool DENSE, typename RT>
-__device__ __forceinline__ void otw_control(OtwLds<W, RT> &S, OtwCtl &k, const OtwArgs &a, const OtwEnv &e,
-                                            int pt, int j0, int pflags, double rf_min, int rf_idx, double sentinel,
-                                            bool spec_launched) {
+__device__ __forceinline__ OtwSettled otw_settle(OtwLds<W, RT> &S, double *R, double *C, OtwCtl &k, const OtwArgs &a,
+                                                 const OtwEnv &e, int pt, int j0, int pflags, double rf_min, int rf_idx,
+                                                 double sentinel) {
     const int c = e.c, lane = e.lane;
     const double inf = INFINITY;
     const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
@@ -688,11 +699,11 @@ __device__ __forceinline__ void otw_control(OtwLds<W, RT> &S, OtwCtl &k, const O
     double cl = 0.0, cf_min = inf;
     int cf_idx = 0x7fffffff;
     // last cell of the row strip = acc[t][j0]; of the column chain = acc[t-1][jn] (Both) or acc[t][jn]
-    const double row_last = do_row ? rfl(S.R[swz<W>(j0)]) : 0.0;
-    if (do_row && !col_active && lane == 0) S.C[swz<W>(pt)] = row_last;  // column j0 gains row t
+    const double row_last = do_row ? rfl(R[swz<W>(j0)]) : 0.0;
+    if (do_row && !col_active && lane == 0) C[swz<W>(pt)] = row_last;  // column j0 gains row t
     if (col_active) {
         const int ncc = nc - (do_row ? 1 : 0);
-        cl = (ncc > 0) ? rfl(S.C[swz<W>(k1c + ncc - 1)]) : ((k1c > 0) ? sentinel : inf);
+        cl = (ncc > 0) ? rfl(C[swz<W>(k1c + ncc - 1)]) : ((k1c > 0) ? sentinel : inf);
         cf_min = rfl(S.cfresh_min);
         cf_idx = __builtin_amdgcn_readfirstlane(S.cfresh_idx);
         if (do_row) {
@@ -700,7 +711,7 @@ __device__ __forceinline__ void otw_control(OtwLds<W, RT> &S, OtwCtl &k, const O
             const double av = vmin(row_last + d, rfl(S.corner_pa));
             cl = vmin(av, cl + d);  // cl was the value of (t-1, jn), or the sentinel carry
             if (lane == 0) {
-                S.C[swz<W>(pt)] = cl;
+                C[swz<W>(pt)] = cl;
                 if (DENSE) {
                     const long long o = ((long long)e.b * e.live_cap + pt) * e.N + jn;
                     a.dense_acc[o] = cl;
@@ -708,41 +719,250 @@ __device__ __forceinline__ void otw_control(OtwLds<W, RT> &S, OtwCtl &k, const O
                 }
             }
         }
-        if (lane == 0) S.R[swz<W>(jn)] = cl;  // row t gains column jn
+        if (lane == 0) R[swz<W>(jn)] = cl;  // row t gains column jn
         k.cols += 1;
         k.cells += nc;
     }
-    k.spec_j = spec_launched ? j0 + 1 : -1;  // what wave 1 computed on the side, if anything
-    k.spec_t = pt;
-    if (stop) {
+    // row band: fresh from this step's row strip, plus the corner a column strip appended;
+    // column band: fresh from this step's column strip (its corner cell is outside the
+    // chain), or the old band plus the row strip's last cell
+    OtwSettled o;
+    o.row_fresh = do_row;
+    o.rf_min = rf_min;
+    o.rf_idx = rf_idx;
+    o.col_fresh = col_active;
+    o.cf_min = cf_min;
+    o.cf_idx = cf_idx;
+    o.row_corner = col_active;
+    o.rc = cl;
+    o.col_corner = do_row;
+    o.cc = col_active ? cl : row_last;
+    o.stop = stop;
+    return o;
+}
+
+// Second half: decide() (or the stop at the reference's end) and the next plan.
+template <int W, typename RT>
+__device__ __forceinline__ void otw_finish(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, int pt, int jn,
+                                           const OtwSettled &o, bool spec = false) {
+    if (o.stop) {
         k.status = RTS_STOP_REF_END;
         k.t = pt;
         k.j = jn;
         k.pending_col = 0;
     } else {
-        // row band: fresh from this step's row strip, plus the corner a column strip appended;
-        // column band: fresh from this step's column strip (its corner cell is outside the
-        // chain: Both step, or a speculative strip), or the old band plus the row strip's last cell
-        otw_decide<W, RT>(S, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl, do_row,
-                          col_active ? cl : row_last, false);
+        otw_decide<W, RT>(S.R, S.C, k, e, pt, jn, o.row_fresh, o.rf_min, o.rf_idx, o.col_fresh, o.cf_min, o.cf_idx, o.row_corner,
+                          o.rc, o.col_corner, o.cc, false);
     }
-    otw_make_plan<W, RT>(S, k, e);
+    k.spec_valid = spec && !o.stop;  // the shadow strips computed during this control phase belong to (k.t, k.j)
+    otw_make_plan<W, RT>(S, k, e, spec);
 }
 
-template <int W, int NW, bool DENSE, typename RT>
+// ---- pipelined kernel ---------------------------------------------------------------------------------------------
+// Cost buffers are keyed by row / column parity instead of by step: Dr[r & 1] holds the costs of live row r and
+// Dc[q & 1] those of reference column q, at ring positions by column / row index.  Invariant at the start of the step
+// that leaves the state at (t, j), for every move it can make:
+//     rows t+1 and t+2 over columns [j-c+1, j+1],  columns j+1 and j+2 over rows [t-c+1, t+1].
+// The step planned to end at (pt, jn) therefore finds the costs of its own strips and of the strips speculated during
+// it already there, and the helpers only restore the invariant for (pt, jn): one new row (pt+2) if t advanced, one new
+// column (jn+2) if j advanced, and the one or two single cells by which the kept rows / columns grew.  None of that is
+// read before the next step, so it is off the critical path.
+template <int W, typename RT>
+__device__ __forceinline__ void otw_cost_row(OtwLds<W, RT> &S, const OtwEnv &e, int r, int k_lo, int k_hi, double *Drow,
+                                             int hidx, int hn) {
+    if (r >= e.live_len || r >= e.live_cap) return;  // never consumed
+    if (k_lo < 0) k_lo = 0;
+    if (k_hi > e.N - 1) k_hi = e.N - 1;
+    if (k_lo + hidx > k_hi) return;
+    double lf[kF];
+#pragma unroll
+    for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][r & (W - 1)];
+    for (int ka = k_lo + hidx; ka <= k_hi; ka += 2 * hn) {  // two cells in flight per thread
+        const int kb = ka + hn;
+        const int kb_c = (kb <= k_hi) ? kb : ka;
+        double ra[kF], rb[kF];
+#pragma unroll
+        for (int f = 0; f < kF; f++) {
+            ra[f] = (double)S.refw[f][ka & (W - 1)];
+            rb[f] = (double)S.refw[f][kb_c & (W - 1)];
+        }
+        const double da = cell_cost(lf, ra, e.euclid), db = cell_cost(lf, rb, e.euclid);
+        Drow[swz<W>(ka)] = da;
+        if (kb <= k_hi) Drow[swz<W>(kb)] = db;
+    }
+}
+template <int W, typename RT>
+__device__ __forceinline__ void otw_cost_col(OtwLds<W, RT> &S, const OtwEnv &e, int q, int r_lo, int r_hi, double *Dcol,
+                                             int hidx, int hn) {
+    if (q >= e.N) return;
+    const int lim = (e.live_len < e.live_cap) ? e.live_len : e.live_cap;
+    if (r_lo < 0) r_lo = 0;
+    if (r_hi > lim - 1) r_hi = lim - 1;
+    if (r_lo + hidx > r_hi) return;
+    double rf[kF];
+#pragma unroll
+    for (int f = 0; f < kF; f++) rf[f] = (double)S.refw[f][q & (W - 1)];
+    for (int ra_ = r_lo + hidx; ra_ <= r_hi; ra_ += 2 * hn) {
+        const int rb_ = ra_ + hn;
+        const int rb_c = (rb_ <= r_hi) ? rb_ : ra_;
+        double la[kF], lb[kF];
+#pragma unroll
+        for (int f = 0; f < kF; f++) {
+            la[f] = (double)S.livew[f][ra_ & (W - 1)];
+            lb[f] = (double)S.livew[f][rb_c & (W - 1)];
+        }
+        const double da = cell_cost(la, rf, e.euclid), db = cell_cost(lb, rf, e.euclid);
+        Dcol[swz<W>(ra_)] = da;
+        if (rb_ <= r_hi) Dcol[swz<W>(rb_)] = db;
+    }
+}
+template <int W, typename RT>
+__device__ __forceinline__ double otw_cost_cell(OtwLds<W, RT> &S, const OtwEnv &e, int r, int q) {
+    double lf[kF], rf[kF];
+#pragma unroll
+    for (int f = 0; f < kF; f++) {
+        lf[f] = (double)S.livew[f][r & (W - 1)];
+        rf[f] = (double)S.refw[f][q & (W - 1)];
+    }
+    return cell_cost(lf, rf, e.euclid);
+}
+
+// Establish the invariant for (t, j) from nothing (launch prologue, all threads).
+template <int W, typename RT>
+__device__ __forceinline__ void otw_costs_prime(OtwLds<W, RT> &S, const OtwEnv &e, int t, int j, int hidx, int hn) {
+    const int c = e.c;
+    otw_cost_row<W, RT>(S, e, t + 1, j - c + 1, j + 1, S.Dr[(t + 1) & 1], hidx, hn);
+    otw_cost_row<W, RT>(S, e, t + 2, j - c + 1, j + 1, S.Dr[(t + 2) & 1], hidx, hn);
+    otw_cost_col<W, RT>(S, e, j + 1, t - c + 1, t + 1, S.Dc[(j + 1) & 1], hidx, hn);
+    otw_cost_col<W, RT>(S, e, j + 2, t - c + 1, t + 1, S.Dc[(j + 2) & 1], hidx, hn);
+}
+
+// Restore the invariant for (pt, jn) after the move the plan describes (helper waves).
+template <int W, typename RT>
+__device__ __forceinline__ void otw_costs_advance(OtwLds<W, RT> &S, const OtwEnv &e, int pt, int jn, bool do_row,
+                                                  bool do_col, int hidx, int hn) {
+    const int c = e.c;
+    const int lim = (e.live_len < e.live_cap) ? e.live_len : e.live_cap;
+    if (do_row) otw_cost_row<W, RT>(S, e, pt + 2, jn - c + 1, jn + 1, S.Dr[(pt + 2) & 1], hidx, hn);
+    if (do_col) otw_cost_col<W, RT>(S, e, jn + 2, pt - c + 1, pt + 1, S.Dc[(jn + 2) & 1], hidx, hn);
+    // single cells, on the last threads (the first ones are the busiest above)
+    if (hidx == hn - 1 && pt + 1 < lim && jn + 1 < e.N) {  // (pt+1, jn+1): kept row pt+1 and kept column jn+1 both grow
+        const double d = otw_cost_cell<W, RT>(S, e, pt + 1, jn + 1);
+        S.Dr[(pt + 1) & 1][swz<W>(jn + 1)] = d;
+        S.Dc[(jn + 1) & 1][swz<W>(pt + 1)] = d;
+    }
+    if (hidx == hn - 2) {
+        if (do_row && !do_col) {  // kept column jn+2 gains row pt+1
+            if (pt + 1 < lim && jn + 2 < e.N) S.Dc[(jn + 2) & 1][swz<W>(pt + 1)] = otw_cost_cell<W, RT>(S, e, pt + 1, jn + 2);
+        } else if (do_col && !do_row) {  // kept row pt+2 gains column jn+1
+            if (pt + 2 < lim && jn + 1 < e.N) S.Dr[(pt + 2) & 1][swz<W>(jn + 1)] = otw_cost_cell<W, RT>(S, e, pt + 2, jn + 1);
+        }
+    }
+}
+
+// A speculative strip (during the step that leaves the state at (pt, jn)): the strip the next Row-only step (row
+// pt+1, pos = jn) or Column-only step (column jn+1, pos = pt) would run, without its last cell `pos`, from the band --
+// whose slots below `pos` are final when the speculating wave starts -- into the shadow; plus what wave 0 needs to
+// finish that step: the strip's argmin and the cost of the cell left out.
+template <int W>
+__device__ __forceinline__ void otw_spec_strip(const double *Dv, const double *band, double *shadow, int pos, int c,
+                                               int lane, double sentinel, OtwSpecOut *out) {
+    const int k1 = (pos - c + 1 > 0) ? pos - c + 1 : 0;
+    double fm;
+    int fi;
+    const double d_last = Dv[swz<W>(pos)];
+    strip_chain<W, false, true>(Dv, band, shadow, k1, pos - k1, (k1 > 0) ? sentinel : (double)INFINITY, lane, k1, fm, fi,
+                                nullptr, nullptr, 0);
+    if (lane == 0) {
+        out->min = fm;
+        out->idx = fi;
+        out->d = d_last;
+    }
+}
+
+// A *hit* step (wave 0): this Row-only / Column-only step's strip, all cells but the last, is the shadow that the plan
+// has just made the band.  Finish the last cell -- from register copies of the three old-band slots it depends on,
+// so the old band's buffer is free for the next speculation straight away -- and hand decide() the strip's argmin.
+template <int W, typename RT>
+__device__ __forceinline__ OtwSettled otw_settle_hit(double *R, double *C, const OtwSpecOut *ex, OtwCtl &k, const OtwEnv &e,
+                                                     int pt, int j0, bool is_row, double sentinel) {
+    const int c = e.c, lane = e.lane;
+    const double inf = INFINITY;
+    const int jn = j0 + (is_row ? 0 : 1);
+    const int pos = is_row ? j0 : pt;                    // band position of the strip's last cell
+    const int k1 = (pos - c + 1 > 0) ? pos - c + 1 : 0;  // strip = [k1, pos]; the shadow holds [k1, pos-1]
+    const int n = pos - k1;
+    double *band = is_row ? R : C;
+    double *other = is_row ? C : R;
+    if (e.deferred_update && k.pend_dir != -2) {  // livenote_v2.py:149-155
+        k.run_count = (k.pend_dir == k.prev) ? k.run_count + 1 : 1;
+        if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
+        k.pend_dir = -2;
+    }
+    const double d = rfl(ex->d);
+    const double smin = rfl(ex->min);
+    const int sidx = __builtin_amdgcn_readfirstlane(ex->idx);
+    const double prev = (n > 0) ? rfl(band[swz<W>(pos - 1)]) : ((k1 > 0) ? sentinel : inf);
+    // row hit: cell (pt, j0), "side" = up; column hit: cell (pt, jn), "side" = left -- in the chain's order
+    // min(min(side + d, diag + 2d), previous cell of the strip + d)
+    const double side = k.cA + d;
+    const double diag = (pos > 0) ? (is_row ? k.cL : k.cU) + 2 * d : inf;
+    const double cl = vmin(vmin(side, diag), prev + d);
+    if (lane == 0) {
+        band[swz<W>(pos)] = cl;
+        other[swz<W>(is_row ? pt : jn)] = cl;  // column j0 gains row pt / row pt gains column jn
+    }
+    if (is_row) {
+        k.rows += 1;
+        k.consumed = pt + 1;
+        k.cU = k.cA;
+        k.cL = prev;
+    } else {
+        k.cols += 1;
+        k.cL = k.cA;
+        k.cU = prev;
+    }
+    k.cA = cl;
+    k.cells += n + 1;
+    OtwSettled o;
+    o.row_fresh = is_row;
+    o.col_fresh = !is_row;
+    o.rf_min = o.cf_min = smin;
+    o.rf_idx = o.cf_idx = sidx;
+    o.row_corner = o.col_corner = true;
+    o.rc = o.cc = cl;
+    o.stop = false;
+    return o;
+}
+
+template <int W, int NW, bool DENSE, typename RT, bool SPEC>
 __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
+    static_assert(!SPEC || (NW >= 8 && !DENSE), "the pipelined kernel needs 8 waves and no dense mirror");
     constexpr int NT = 64 * NW;
-    // Waves >= HW0 pre-compute the next step's cell costs while waves 0/1 run the chains.  With fewer
-    // than 4 waves there are no spare ones and every wave does its share after its chain.
-    constexpr int HW0 = (NW >= 4) ? 2 : 0;
+    // Waves >= HW0 pre-compute the next step's cell costs while waves 0/1 run the chains (pipelined kernel:
+    // wave 2 runs the speculative column strip).  With fewer than 4 waves there are no spare ones and every
+    // wave does its share after its chain.
+    constexpr int HW0 = SPEC ? 3 : (NW >= 4) ? 2 : 0;
     constexpr int NHELP = 64 * (NW - HW0);
-#ifdef RTS_OTW_STAMPS
-    long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 1
+    long long stamp_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int stamp_base = 0;
     long long stamp_last = (long long)__builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
+#if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 2
+    long long lw_hit = 0, lb_hit = 0, lw_oth = 0, lb_oth = 0, ln_hit = 0, ln_oth = 0, l_last = 0;
+    long long lo_work = 0, lo_t0 = 0;  // waves 1, 2, 3: own work in hit steps
+#define RTS_LW_BEGIN() do { lo_t0 = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
+#define RTS_LW_END(hit) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); if (hit) lo_work += t_ - lo_t0; } while (0)
+#else
+#define RTS_LW_BEGIN() do { } while (0)
+#define RTS_LW_END(hit) do { } while (0)
+#endif
     extern __shared__ __align__(16) unsigned char smem_raw[];
     OtwLds<W, RT> &S = *reinterpret_cast<OtwLds<W, RT> *>(smem_raw);
+    constexpr size_t kSpecOff = (sizeof(OtwLds<W, RT>) + 15) & ~(size_t)15;
+    OtwSpecLds<W> &SP = *reinterpret_cast<OtwSpecLds<W> *>(smem_raw + kSpecOff);  // only touched when SPEC
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -806,8 +1026,9 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     k.rb_idx = 0;
     k.cb_idx = 0;
     k.pfl0 = k.pfl1 = k.pfr0 = k.pfr1 = 0.0;
-    k.spec_t = -1;
-    k.spec_j = -1;
+    k.spec_valid = 0;
+    k.ri = k.ci = 0;
+    k.cA = k.cU = k.cL = inf;
 
     if (k.status == RTS_STOP_REF_END) return;  // sticky; the reference's callers stop inserting
     if (k.status == RTS_LIVE_OVERFLOW) {       // otw_eran.py:50-55: t keeps counting inserts
@@ -823,15 +1044,16 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     for (int i = tid; i < OtwLds<W, RT>::SWZ; i += NT) {  // no uninitialised LDS ever reaches the arithmetic
         S.R[i] = 0.0;
         S.C[i] = 0.0;
-        S.Sh[i] = 0.0;
         S.Dr[0][i] = S.Dr[1][i] = S.Dc[0][i] = S.Dc[1][i] = 0.0;
+        if (SPEC) SP.ShR[i] = SP.ShC[i] = 0.0;
     }
     __syncthreads();
     {
         const int lo_l = (k.t - c + 1 > 0) ? k.t - c + 1 : 0;
         const int lo_r = (k.j - c + 1 > 0) ? k.j - c + 1 : 0;
-        k.live_hi = (k.t + 2 < live_len - 1) ? k.t + 2 : live_len - 1;
-        k.ref_hi = (k.j + 2 < N - 1) ? k.j + 2 : N - 1;
+        constexpr int kAhead = SPEC ? 3 : 2;  // frames the first step's cost computations reach past (t, j)
+        k.live_hi = (k.t + kAhead < live_len - 1) ? k.t + kAhead : live_len - 1;
+        k.ref_hi = (k.j + kAhead < N - 1) ? k.j + kAhead : N - 1;
         for (int idx = tid; idx < (k.live_hi - lo_l + 1) * kF; idx += NT) {
             const int fr = lo_l + idx / kF, f = idx % kF;
             S.livew[f][fr & (W - 1)] = (RT)otw_load_feat(a.live, a.live_f64, e.live_base + (long long)fr * kF + f);
@@ -881,7 +1103,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             k.cb_idx = 0;
             __builtin_amdgcn_wave_barrier();
             if (a.mode == RTS_MODE_SET_LIVE)
-                otw_decide<W, RT>(S, k, e, 0, 0, false, 0.0, 0, false, 0.0, 0, false, 0.0, false, 0.0, true);
+                otw_decide<W, RT>(S.R, S.C, k, e, 0, 0, false, 0.0, 0, false, 0.0, 0, false, 0.0, false, 0.0, true);
         } else {  // band minima are not persisted: rebuild them from the reloaded bands
             for (int which = 0; which < 2; which++) {
                 const int hi = which ? k.t : k.j;
@@ -905,71 +1127,202 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     __syncthreads();
     // prime the cost buffers for the first step (all threads), then publish its plan
     int buf = 0;
-    otw_precompute<W, RT>(S, e, S.t, S.j, S.Dr[0], S.Dc[0], tid, NT);
-    if (wave == 0) otw_make_plan<W, RT>(S, k, e);
+    if constexpr (SPEC) {
+        otw_costs_prime<W, RT>(S, e, S.t, S.j, tid, NT);
+        if (wave == 0) {
+            k.cA = rfl(S.R[swz<W>(k.j)]);
+            k.cU = (k.t > 0) ? rfl(S.C[swz<W>(k.t - 1)]) : inf;
+            k.cL = (k.j > 0) ? rfl(S.R[swz<W>(k.j - 1)]) : inf;
+            otw_make_plan<W, RT>(S, k, e, true);
+        }
+    } else {
+        otw_precompute<W, RT>(S, e, S.t, S.j, S.Dr[0], S.Dc[0], tid, NT);
+        if (wave == 0) otw_make_plan<W, RT>(S, k, e);
+    }
     __syncthreads();
 
-    if constexpr (NW >= 4) {
+    int sp = 0;  // pipelined kernel: step parity (plan slot read this step; speculation results go to [sp ^ 1])
+    if constexpr (SPEC) {
+        // ---- pipelined step loops.  While wave 0 runs the control work of a step, wave 1 already runs the row strip
+        // the next step needs if it turns out Row-only and wave 2 the column strip it needs if it turns out
+        // Column-only -- each minus its last cell, which depends on the corner wave 0 is computing -- into the shadow
+        // buffers, and the helpers extend the cost buffers one row / column further out.  The next Row-only or
+        // Column-only step is then a *hit*: its shadow becomes the band (the plan flips the buffer index), wave 0
+        // finishes the last cell from registers and goes straight to decide(), and the other waves start the next
+        // speculation at once -- no wave reads anything a hit step's wave 0 writes (the guard in strip_chain), so a hit
+        // step has a single barrier, at its end.  Both steps, stop steps and the first step of a launch run their
+        // chains first, as in the plain kernel, then speculate during their control phase.  Values are bit-identical
+        // either way: a speculative strip is the same chain on the same inputs, the last cell the chain's own expression.
+        if (wave >= HW0) {
+            for (;;) {
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[sp]);
+                if (pflags & kPlanExit) break;
+                const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
+                RTS_LW_BEGIN();
+                if (!(pflags & kPlanHit)) __syncthreads();  // this step's chains have read their cost buffers
+                if (!(pflags & kPlanStop))
+                    otw_costs_advance<W, RT>(S, e, pt, j0 + (do_col ? 1 : 0), do_row, do_col, tid - 64 * HW0, NHELP);
+                RTS_LW_END(pflags & kPlanHit);
+                __syncthreads();
+                sp ^= 1;
+            }
+        } else if (wave == 1) {
+            for (;;) {
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[sp]);
+                if (pflags & kPlanExit) break;
+                const int jn = j0 + ((pflags & kPlanCol) ? 1 : 0);
+                double *R = (pflags & kPlanRi) ? SP.ShR : S.R, *Rsh = (pflags & kPlanRi) ? S.R : SP.ShR;
+                RTS_LW_BEGIN();
+                if (!(pflags & kPlanHit)) {
+                    if ((pflags & (kPlanRow | kPlanCol | kPlanStop)) == (kPlanRow | kPlanCol))  // Both step
+                        otw_col_strip<W, DENSE, RT>(S, (pflags & kPlanCi) ? SP.ShC : S.C, a, e, S.Dc[(j0 + 1) & 1], pt,
+                                                    j0 + 1, true, sentinel);
+                    __syncthreads();
+                }
+                if (!(pflags & kPlanStop) && pt + 1 < live_len && pt + 1 < a.live_cap)  // row pt+1 over [.., jn-1]
+                    otw_spec_strip<W>(S.Dr[(pt + 1) & 1], R, Rsh, jn, c, lane, sentinel, &SP.row[sp ^ 1]);
+                RTS_LW_END(pflags & kPlanHit);
+                __syncthreads();
+                sp ^= 1;
+            }
+        } else if (wave == 2) {
+            for (;;) {
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[sp]);
+                if (pflags & kPlanExit) break;
+                const int jn = j0 + ((pflags & kPlanCol) ? 1 : 0);
+                double *C = (pflags & kPlanCi) ? SP.ShC : S.C, *Csh = (pflags & kPlanCi) ? S.C : SP.ShC;
+                RTS_LW_BEGIN();
+                if (!(pflags & kPlanHit)) __syncthreads();
+                if (!(pflags & kPlanStop) && jn + 1 < N)  // column jn+1 over rows [.., pt-1]
+                    otw_spec_strip<W>(S.Dc[(jn + 1) & 1], C, Csh, pt, c, lane, sentinel, &SP.col[sp ^ 1]);
+                RTS_LW_END(pflags & kPlanHit);
+                __syncthreads();
+                sp ^= 1;
+            }
+        } else {
+            // wave 0.  Diagnostic stamps: slots 0..5 = hit steps, 8..13 = other steps
+            // (0 end-of-step barrier wait, 1 chains, 2 mid-step barrier wait, 3 settle, 4 decide, 5 plan); 6 / 14 = counts
+            for (;;) {
+                RTS_STAMP2(0);
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[sp]);
+                if (pflags & kPlanExit) break;
+                const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
+                const bool stop = (pflags & kPlanStop) != 0;
+                const int jn = j0 + (do_col ? 1 : 0);
+                double *R = (pflags & kPlanRi) ? SP.ShR : S.R, *C = (pflags & kPlanCi) ? SP.ShC : S.C;
+                OtwSettled o;
+#if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 1
+                stamp_base = (pflags & kPlanHit) ? 0 : 8;
+                if (stamp_base) stamp_sum[14] += 1; else stamp_sum[6] += 1;
+#endif
+                if (pflags & kPlanHit) {
+                    o = otw_settle_hit<W, RT>(R, C, do_row ? &SP.row[sp] : &SP.col[sp], k, e, pt, j0, do_row, sentinel);
+                } else {
+                    double rf_min = inf;
+                    int rf_idx = 0x7fffffff;
+                    if (do_row)
+                        otw_row_strip<W, DENSE, RT>(R, a, e, S.Dr[pt & 1], pt, j0, jn, sentinel, rf_min, rf_idx);
+                    else if (do_col && !stop)
+                        otw_col_strip<W, DENSE, RT>(S, C, a, e, S.Dc[jn & 1], pt, jn, false, sentinel);
+                    RTS_STAMP(9);
+                    __syncthreads();
+                    RTS_STAMP(10);
+                    o = otw_settle<W, DENSE, RT>(S, R, C, k, a, e, pt, j0, pflags, rf_min, rf_idx, sentinel);
+                    // the three band slots the next hit step's last cell depends on (reads follow this wave's own writes)
+                    k.cA = rfl(R[swz<W>(jn)]);
+                    k.cU = (pt > 0) ? rfl(C[swz<W>(pt - 1)]) : inf;
+                    k.cL = (jn > 0) ? rfl(R[swz<W>(jn - 1)]) : inf;
+                }
+                RTS_STAMP2(3);
+                if (o.stop) {
+                    k.status = RTS_STOP_REF_END;
+                    k.t = pt;
+                    k.j = jn;
+                    k.pending_col = 0;
+                } else {
+                    otw_decide<W, RT>(R, C, k, e, pt, jn, o.row_fresh, o.rf_min, o.rf_idx, o.col_fresh, o.cf_min, o.cf_idx,
+                                      o.row_corner, o.rc, o.col_corner, o.cc, false);
+                }
+                RTS_STAMP2(4);
+                k.spec_valid = !o.stop;  // the shadows being computed during this step belong to (k.t, k.j)
+                otw_make_plan<W, RT>(S, k, e, true, sp ^ 1);
+                RTS_STAMP2(5);
+#if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 2
+                {
+                    const long long t0_ = (long long)__builtin_amdgcn_s_memtime();
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __syncthreads();
+                    const long long t1_ = (long long)__builtin_amdgcn_s_memtime();
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    if (pflags & kPlanHit) {
+                        lw_hit += t0_ - l_last;
+                        lb_hit += t1_ - t0_;
+                        ln_hit += 1;
+                    } else {
+                        lw_oth += t0_ - l_last;
+                        lb_oth += t1_ - t0_;
+                        ln_oth += 1;
+                    }
+                    l_last = t1_;
+                }
+#else
+                __syncthreads();
+#endif
+                sp ^= 1;
+            }
+        }
+    } else if constexpr (NW >= 4) {
         // ---- role-specialised step loops.  Every wave runs only its own role's code between the two barriers of
         // a step (a step = one row strip and/or one column strip + one decide()), so each loop keeps only its own
         // values live: helpers pre-compute costs, wave 1 runs the column strip of Both steps, wave 0 runs the
         // (other) strip and then the control phase.  All of them read the plan wave 0 published.
-        constexpr bool kSpec = !DENSE;  // the dense mirror must only ever see real strips
         if (wave >= HW0) {
             for (;;) {
-                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
-                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[0]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[0]),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[0]);
                 if (pflags & kPlanExit) break;
                 const int jn = j0 + ((pflags & kPlanCol) ? 1 : 0);
                 if (!(pflags & kPlanStop))
                     otw_precompute<W, RT>(S, e, pt, jn, S.Dr[buf ^ 1], S.Dc[buf ^ 1], tid - 64 * HW0, NHELP);
-                if (!(pflags & kPlanHit)) __syncthreads();  // strips complete (a hit step has none)
-                __syncthreads();                            // next costs complete, next plan published
+                __syncthreads();  // strips and next costs complete
+                __syncthreads();  // next plan published
                 buf ^= 1;
             }
         } else if (wave == 1) {
             for (;;) {
-                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
-                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[0]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[0]),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[0]);
                 if (pflags & kPlanExit) break;
-                const int kind = pflags & (kPlanRow | kPlanCol | kPlanStop);
-                if (kind == (kPlanRow | kPlanCol)) {  // Both step: the column strip
-                    otw_col_strip<W, DENSE, RT>(S, a, e, S.Dc[buf], pt, j0 + 1, true, sentinel);
-                } else if (kSpec && a.spec && kind == kPlanRow && j0 + 1 < N) {
-                    // Row-only step: run the column strip the next step needs if decide() says "Column"
-                    // (~70 % in steady state); its costs are already in Dc
-                    otw_spec_col_strip<W, RT>(S, e, S.Dc[buf], pt, sentinel);
-                }
-                if (!(pflags & kPlanHit)) __syncthreads();
+                if ((pflags & (kPlanRow | kPlanCol | kPlanStop)) == (kPlanRow | kPlanCol))  // Both step
+                    otw_col_strip<W, DENSE, RT>(S, S.C, a, e, S.Dc[buf], pt, j0 + 1, true, sentinel);
+                __syncthreads();
                 __syncthreads();
                 buf ^= 1;
             }
         } else {
             for (;;) {
                 RTS_STAMP(0);
-                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
-                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[0]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[0]),
+                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[0]);
                 if (pflags & kPlanExit) break;
-                if (kSpec && (pflags & kPlanHit)) {  // a step whose strip already exists: control only, one barrier
-                    otw_control_hit<W, RT>(S, k, e, pt, j0, S.Dc[buf], sentinel);
-                    __syncthreads();
-                    buf ^= 1;
-                    continue;
-                }
                 const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
                 const bool stop = (pflags & kPlanStop) != 0;
                 const int jn = j0 + (do_col ? 1 : 0);
                 double rf_min = inf;
                 int rf_idx = 0x7fffffff;
                 if (do_row)
-                    otw_row_strip<W, DENSE, RT>(S, a, e, S.Dr[buf], pt, j0, jn, sentinel, rf_min, rf_idx);
+                    otw_row_strip<W, DENSE, RT>(S.R, a, e, S.Dr[buf], pt, j0, jn, sentinel, rf_min, rf_idx);
                 else if (do_col && !stop)
-                    otw_col_strip<W, DENSE, RT>(S, a, e, S.Dc[buf], pt, jn, false, sentinel);
+                    otw_col_strip<W, DENSE, RT>(S, S.C, a, e, S.Dc[buf], pt, jn, false, sentinel);
                 RTS_STAMP(3);
                 __syncthreads();
                 RTS_STAMP(5);
-                const bool spec_launched = kSpec && a.spec && do_row && !do_col && (j0 + 1 < N);
-                otw_control<W, DENSE, RT>(S, k, a, e, pt, j0, pflags, rf_min, rf_idx, sentinel, spec_launched);
+                const OtwSettled o = otw_settle<W, DENSE, RT>(S, S.R, S.C, k, a, e, pt, j0, pflags, rf_min, rf_idx, sentinel);
+                otw_finish<W, RT>(S, k, e, pt, jn, o);
                 RTS_STAMP(8);
                 __syncthreads();
                 buf ^= 1;
@@ -979,8 +1332,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         // ---- step loop: one iteration = one row strip and/or one column strip + one decide()
         for (;;) {
             RTS_STAMP(0);
-            const int pt = __builtin_amdgcn_readfirstlane(S.plan_t), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0),
-                      pflags = __builtin_amdgcn_readfirstlane(S.plan_flags);
+            const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[0]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[0]),
+                      pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[0]);
             if (pflags & kPlanExit) break;
             const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
             const bool stop = (pflags & kPlanStop) != 0;
@@ -999,8 +1352,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 const double x_in = (k1r > 0) ? sentinel : inf;  // (t, k1r-1) was never evaluated
                 const int lo_arg = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // row band's lower end at decide()
                 const long long dro = ((long long)e.b * a.live_cap + pt) * N + k1r;  // cell (pt, k1r)
-                strip_chain<W, DENSE>(Dr, S.R, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx,
-                                      DENSE ? a.dense_acc + dro : nullptr, DENSE ? a.dense_cost + dro : nullptr, 1);
+                strip_chain<W, DENSE>(Dr, S.R, S.R, k1r, nr, x_in, lane, lo_arg, rf_min, rf_idx, DENSE ? a.dense_acc + dro : nullptr,
+                                      DENSE ? a.dense_cost + dro : nullptr, 1);
                 if (lane == 0 && k1r > 0) S.R[swz<W>(k1r - 1)] = sentinel;
             }
             if (col_active && wave == col_wave) {
@@ -1078,7 +1431,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                     // row band: fresh from this step's row strip, plus the corner a column strip appended;
                     // column band: fresh from this step's column strip (its corner cell is outside the
                     // chain), or the old band plus the row strip's last cell
-                    otw_decide<W, RT>(S, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl,
+                    otw_decide<W, RT>(S.R, S.C, k, e, pt, jn, do_row, rf_min, rf_idx, col_active, cf_min, cf_idx, col_active, cl,
                                   do_row, col_active ? cl : row_last, false);
                 }
                 RTS_STAMP(7);
@@ -1099,15 +1452,24 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         if (je > N - 1) je = N - 1;
         double *bb = a.bands + (size_t)e.b * 2 * (c + 1);
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        const int fl = S.plan_flags[sp];  // pipelined kernel: which buffer of each pair ended up holding the band
+        const double *Rf = (SPEC && (fl & kPlanRi)) ? SP.ShR : S.R, *Cf = (SPEC && (fl & kPlanCi)) ? SP.ShC : S.C;
         for (int i = tid; i <= c; i += NT) {
             const int y = je - c + i, x = te - c + i;
-            bb[i] = (y >= 0) ? S.R[swz<W>(y)] : qnan;
-            bb[(c + 1) + i] = (x >= 0 && x <= t_state) ? S.C[swz<W>(x)] : qnan;
+            bb[i] = (y >= 0) ? Rf[swz<W>(y)] : qnan;
+            bb[(c + 1) + i] = (x >= 0 && x <= t_state) ? Cf[swz<W>(x)] : qnan;
         }
     }
-#ifdef RTS_OTW_STAMPS
+#if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 1
     if (tid == 0 && a.debug)
-        for (int i = 0; i < 12; i++) a.debug[(size_t)e.b * 16 + i] = stamp_sum[i];
+        for (int i = 0; i < 16; i++) a.debug[(size_t)e.b * 16 + i] = stamp_sum[i];
+#endif
+#if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 2
+    if (tid == 0 && a.debug) {
+        long long *dbg = a.debug + (size_t)e.b * 16;
+        dbg[0] = lw_hit, dbg[1] = lb_hit, dbg[2] = ln_hit, dbg[3] = lw_oth, dbg[4] = lb_oth, dbg[5] = ln_oth;
+    }
+    if (a.debug && lane == 0 && wave >= 1 && wave <= 4) a.debug[(size_t)e.b * 16 + 5 + wave] = lo_work;
 #endif
     if (tid == 0) {
         st[RTS_ST_T] = k.t;
@@ -1204,21 +1566,21 @@ struct rts_otw {
     int32_t *hist_len;  // [B]
     long long *debug;   // diagnostic builds only
     double *dense_acc, *dense_cost;  // caller-owned, optional
-    int spec;
+    int spec;           // 1: pipelined kernel (8 waves, no dense mirror); 0: chains and control back to back
 };
 
 namespace rts {
 
-template <int W, int NW, bool DENSE, typename RT>
+template <int W, int NW, bool DENSE, typename RT, bool SPEC>
 static int launch_advance_d(const OtwArgs &args, int B, hipStream_t s) {
-    const size_t smem = sizeof(OtwLds<W, RT>);
+    const size_t smem = SPEC ? ((sizeof(OtwLds<W, RT>) + 15) & ~(size_t)15) + sizeof(OtwSpecLds<W>) : sizeof(OtwLds<W, RT>);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
-        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&otw_advance_kernel<W, NW, DENSE, RT>),
+        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&otw_advance_kernel<W, NW, DENSE, RT, SPEC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
-    hipLaunchKernelGGL((otw_advance_kernel<W, NW, DENSE, RT>), dim3(B), dim3(64 * NW), smem, s, args);
+    hipLaunchKernelGGL((otw_advance_kernel<W, NW, DENSE, RT, SPEC>), dim3(B), dim3(64 * NW), smem, s, args);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -1226,10 +1588,16 @@ static int launch_advance_d(const OtwArgs &args, int B, hipStream_t s) {
 // The dense mirror is a separate instantiation so that the default kernel carries none of its code.
 template <int W, int NW>
 static int launch_advance(const OtwArgs &args, int B, hipStream_t s) {
-    if (args.dense_acc) return launch_advance_d<W, NW, true, double>(args, B, s);
+    if (args.dense_acc) return launch_advance_d<W, NW, true, double, false>(args, B, s);
     // float32 rings only when both inputs are float32: every value then widens back exactly
-    if (!args.ref_f64 && !args.live_f64) return launch_advance_d<W, NW, false, float>(args, B, s);
-    return launch_advance_d<W, NW, false, double>(args, B, s);
+    const bool f32 = !args.ref_f64 && !args.live_f64;
+    if constexpr (NW >= 8) {
+        if (args.spec)
+            return f32 ? launch_advance_d<W, NW, false, float, true>(args, B, s)
+                       : launch_advance_d<W, NW, false, double, true>(args, B, s);
+    }
+    return f32 ? launch_advance_d<W, NW, false, float, false>(args, B, s)
+               : launch_advance_d<W, NW, false, double, false>(args, B, s);
 }
 
 template <int W>
@@ -1313,8 +1681,19 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     while (h->W < c + 12) h->W *= 2;
     h->waves = 8;  // waves 0/1 run the chains, 2..7 pre-compute the next step's costs
     {
+        // The pipelined kernel is the faster one per stream but needs 82 KB of LDS at c = 500, one workgroup per CU;
+        // the plain kernel fits two.  So: pipelined while every stream can have a CU of its own, plain beyond that
+        // (throughput mode).  RTS_OTW_SPEC=0/1 forces either; results are identical.
         const char *sp = getenv("RTS_OTW_SPEC");
-        h->spec = sp ? atoi(sp) : 1;
+        if (sp) {
+            h->spec = atoi(sp) != 0;
+        } else {
+            int dev = 0, n_cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                n_cu = 256;
+            h->spec = B <= n_cu;
+        }
     }
     h->live_cap = 2 * N;
     h->path_cap = 3 * N + 8;  // one point per decide(); decides <= row strips + column strips <= 2N + N

@@ -13,7 +13,7 @@ def build():
     so = os.path.join(DIAG, "librtsync_diag.so")
     src = [os.path.join(ROOT, "real_time_audio_sync_amd", "csrc", f) for f in ("common.cpp", "otw.hip")]
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-DRTS_OTW_STAMPS", "-o", so]
+           "-ffp-contract=off", "-fno-fast-math", "-DRTS_OTW_STAMPS=%s" % os.environ.get("RTS_DIAG_LEVEL", "1"), "-o", so]
     for s in src:
         cmd += ["-x", "hip", s]
     subprocess.check_call(cmd)
@@ -46,8 +46,8 @@ def main():
         buf[b, :l.shape[1]] = torch.from_numpy(l.T.copy()).float()
     live_d = buf.to(dev)
     len_d = torch.tensor([l.shape[1] for l in lives], dtype=torch.int32, device=dev)
-    names = ["barrier3+read plan", "-", "-", "chain (waves 0/1)", "precompute (helpers)", "barrier2", "fixup", "decide", "plan+refill"]
-    for waves in (1, 2, 4, 8):
+    names = ["barrier 2 wait + plan", "-", "-", "phase A (chain / install)", "-", "barrier 1 wait", "-", "-", "control"]
+    for waves in (8,):
         h = vp()
         assert L.rts_otw_create(ref_d.data_ptr(), 0, 12, N, B, c, 3, 0, 0, ctypes.byref(h)) == 0
         L.rts_otw_set_waves(h, waves)
@@ -60,11 +60,22 @@ def main():
         L.rts_otw_read_states(h, st.ctypes.data, None)
         d = dbg.cpu().numpy().astype(np.float64)
         frames = st[:, 8].sum()
-        steps = d[:, :9].sum(axis=1)
-        tot = d[:, :9].sum()
-        print("waves=%d: wave-0 cycles (100 MHz ticks?) per frame: %.0f ; shares:" % (waves, tot / frames))
-        for i, nme in enumerate(names):
-            print("   %-18s %6.1f %%   (%.0f per frame)" % (nme, 100 * d[:, i].sum() / tot, d[:, i].sum() / frames))
+        if os.environ.get("RTS_DIAG_LEVEL", "1") == "2":
+            for base, label in ((0, "hit steps"), (3, "other steps")):
+                n = max(d[:, base + 2].sum(), 1)
+                print("%s: %d  wave-0 work %.0f cycles, end-of-step barrier wait %.0f cycles" % (label, n, d[:, base].sum() / n, d[:, base + 1].sum() / n))
+            n = max(d[:, 2].sum(), 1)
+            print("hit steps, own work: wave 1 (row speculation) %.0f, wave 2 (column speculation) %.0f, wave 3 %.0f, wave 4 %.0f (helpers)"
+                  % tuple(d[:, 6 + i].sum() / n for i in range(4)))
+            return
+        nm = ["barrier-2 wait", "phase A (chain / install)", "barrier-1 wait", "settle", "decide", "plan + refill"]
+        for base, label in ((0, "hit steps"), (8, "other steps")):
+            n = d[:, base + 6].sum()
+            tot = d[:, base:base + 6].sum()
+            print("%s: %d (%.1f per frame), %.0f cycles per step" % (label, n, n / frames, tot / max(n, 1)))
+            for i, x in enumerate(nm):
+                print("   %-28s %7.0f cycles  %5.1f %%" % (x, d[:, base + i].sum() / max(n, 1), 100 * d[:, base + i].sum() / max(tot, 1)))
+        print("band argmin recomputes per frame: %.3f" % (st[:, 15].sum() / frames))
 
 
 if __name__ == "__main__":
