@@ -576,8 +576,20 @@ __device__ __forceinline__ void otw_decide(const double *R, const double *C, Otw
 
 // Plan for the next step from the current register state (wave 0); lane 0 publishes it.
 template <int W, typename RT>
-__device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, bool spec = false,
-                                              int slot = 0) {
+__device__ __forceinline__ void otw_refill(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, int need_live, int need_ref) {
+    const int need_l = (need_live < e.live_len - 1) ? need_live : e.live_len - 1;
+    const int need_r = (need_ref < e.N - 1) ? need_ref : e.N - 1;
+    if (need_l > k.live_hi) otw_commit_live<W, RT>(S, k, e);
+    if (need_r > k.ref_hi) otw_commit_ref<W, RT>(S, k, e);
+}
+
+struct OtwPlan {
+    int t, j0, flags;
+};
+
+template <int W, typename RT>
+__device__ __forceinline__ OtwPlan otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, bool spec = false,
+                                                 int slot = 0) {
     int flags = 0, pt = k.t;
     if (k.status != RTS_RUNNING) {
         flags = kPlanExit;
@@ -615,15 +627,17 @@ __device__ __forceinline__ void otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, const
             S.j = k.j;
         }
     }
-    // keep the rings one frame ahead of what this step's cost pre-computation will read
-    if (!(flags & kPlanExit)) {
+    // keep the rings one frame ahead of what this step's cost pre-computation will read (the pipelined kernel
+    // leaves the rings to its first helper wave)
+    if (!spec && !(flags & kPlanExit)) {
         const int jn_p = k.j + ((flags & kPlanCol) ? 1 : 0);
-        const int ahead = spec ? 2 : 1;  // the pipelined kernel's helpers work one row / column further out
-        const int need_l = (pt + ahead < e.live_len - 1) ? pt + ahead : e.live_len - 1;
-        const int need_r = (jn_p + ahead < e.N - 1) ? jn_p + ahead : e.N - 1;
-        if (need_l > k.live_hi) otw_commit_live<W, RT>(S, k, e);
-        if (need_r > k.ref_hi) otw_commit_ref<W, RT>(S, k, e);
+        otw_refill<W, RT>(S, k, e, pt + 1, jn_p + 1);
     }
+    OtwPlan p;
+    p.t = pt;
+    p.j0 = k.j;
+    p.flags = flags;
+    return p;
 }
 
 // This step's row strip (t, [k1r, j0]) on the calling wave; returns its argmin restricted to the row
@@ -762,18 +776,20 @@ __device__ __forceinline__ void otw_finish(OtwLds<W, RT> &S, OtwCtl &k, const Ot
 // Cost buffers are keyed by row / column parity instead of by step: Dr[r & 1] holds the costs of live row r and
 // Dc[q & 1] those of reference column q, at ring positions by column / row index.  Invariant at the start of the step
 // that leaves the state at (t, j), for every move it can make:
-//     rows t+1 and t+2 over columns [j-c+1, j+1],  columns j+1 and j+2 over rows [t-c+1, t+1].
+//     rows t+1 and t+2 over columns [j-c+1, j+2],  columns j+1 and j+2 over rows [t-c+1, t+2].
 // The step planned to end at (pt, jn) therefore finds the costs of its own strips and of the strips speculated during
 // it already there, and the helpers only restore the invariant for (pt, jn): one new row (pt+2) if t advanced, one new
-// column (jn+2) if j advanced, and the one or two single cells by which the kept rows / columns grew.  None of that is
-// read before the next step, so it is off the critical path.
+// column (jn+2) if j advanced.  The cells by which the *kept* rows / columns must grow are exactly the last cells of
+// those new strips, so the thread that computes one stores it twice.  None of it is read before the next step, so all
+// of this is off the critical path.
 template <int W, typename RT>
-__device__ __forceinline__ void otw_cost_row(OtwLds<W, RT> &S, const OtwEnv &e, int r, int k_lo, int k_hi, double *Drow,
+__device__ __forceinline__ void otw_cost_row(OtwLds<W, RT> &S, const OtwEnv &e, int r, int k_lo, int k_hi, int dual_lo,
                                              int hidx, int hn) {
     if (r >= e.live_len || r >= e.live_cap) return;  // never consumed
     if (k_lo < 0) k_lo = 0;
     if (k_hi > e.N - 1) k_hi = e.N - 1;
     if (k_lo + hidx > k_hi) return;
+    double *Drow = S.Dr[r & 1];
     double lf[kF];
 #pragma unroll
     for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][r & (W - 1)];
@@ -788,17 +804,22 @@ __device__ __forceinline__ void otw_cost_row(OtwLds<W, RT> &S, const OtwEnv &e, 
         }
         const double da = cell_cost(lf, ra, e.euclid), db = cell_cost(lf, rb, e.euclid);
         Drow[swz<W>(ka)] = da;
-        if (kb <= k_hi) Drow[swz<W>(kb)] = db;
+        if (ka >= dual_lo) S.Dc[ka & 1][swz<W>(r)] = da;  // kept column ka gains row r
+        if (kb <= k_hi) {
+            Drow[swz<W>(kb)] = db;
+            if (kb >= dual_lo) S.Dc[kb & 1][swz<W>(r)] = db;
+        }
     }
 }
 template <int W, typename RT>
-__device__ __forceinline__ void otw_cost_col(OtwLds<W, RT> &S, const OtwEnv &e, int q, int r_lo, int r_hi, double *Dcol,
+__device__ __forceinline__ void otw_cost_col(OtwLds<W, RT> &S, const OtwEnv &e, int q, int r_lo, int r_hi, int dual_lo,
                                              int hidx, int hn) {
     if (q >= e.N) return;
     const int lim = (e.live_len < e.live_cap) ? e.live_len : e.live_cap;
     if (r_lo < 0) r_lo = 0;
     if (r_hi > lim - 1) r_hi = lim - 1;
     if (r_lo + hidx > r_hi) return;
+    double *Dcol = S.Dc[q & 1];
     double rf[kF];
 #pragma unroll
     for (int f = 0; f < kF; f++) rf[f] = (double)S.refw[f][q & (W - 1)];
@@ -813,51 +834,36 @@ __device__ __forceinline__ void otw_cost_col(OtwLds<W, RT> &S, const OtwEnv &e, 
         }
         const double da = cell_cost(la, rf, e.euclid), db = cell_cost(lb, rf, e.euclid);
         Dcol[swz<W>(ra_)] = da;
-        if (rb_ <= r_hi) Dcol[swz<W>(rb_)] = db;
+        if (ra_ >= dual_lo) S.Dr[ra_ & 1][swz<W>(q)] = da;  // kept row ra_ gains column q
+        if (rb_ <= r_hi) {
+            Dcol[swz<W>(rb_)] = db;
+            if (rb_ >= dual_lo) S.Dr[rb_ & 1][swz<W>(q)] = db;
+        }
     }
-}
-template <int W, typename RT>
-__device__ __forceinline__ double otw_cost_cell(OtwLds<W, RT> &S, const OtwEnv &e, int r, int q) {
-    double lf[kF], rf[kF];
-#pragma unroll
-    for (int f = 0; f < kF; f++) {
-        lf[f] = (double)S.livew[f][r & (W - 1)];
-        rf[f] = (double)S.refw[f][q & (W - 1)];
-    }
-    return cell_cost(lf, rf, e.euclid);
 }
 
 // Establish the invariant for (t, j) from nothing (launch prologue, all threads).
 template <int W, typename RT>
 __device__ __forceinline__ void otw_costs_prime(OtwLds<W, RT> &S, const OtwEnv &e, int t, int j, int hidx, int hn) {
     const int c = e.c;
-    otw_cost_row<W, RT>(S, e, t + 1, j - c + 1, j + 1, S.Dr[(t + 1) & 1], hidx, hn);
-    otw_cost_row<W, RT>(S, e, t + 2, j - c + 1, j + 1, S.Dr[(t + 2) & 1], hidx, hn);
-    otw_cost_col<W, RT>(S, e, j + 1, t - c + 1, t + 1, S.Dc[(j + 1) & 1], hidx, hn);
-    otw_cost_col<W, RT>(S, e, j + 2, t - c + 1, t + 1, S.Dc[(j + 2) & 1], hidx, hn);
+    const int none = 0x7fffffff;
+    otw_cost_row<W, RT>(S, e, t + 1, j - c + 1, j + 2, none, hidx, hn);
+    otw_cost_row<W, RT>(S, e, t + 2, j - c + 1, j + 2, none, hidx, hn);
+    otw_cost_col<W, RT>(S, e, j + 1, t - c + 1, t + 2, none, hidx, hn);
+    otw_cost_col<W, RT>(S, e, j + 2, t - c + 1, t + 2, none, hidx, hn);
 }
 
-// Restore the invariant for (pt, jn) after the move the plan describes (helper waves).
+// Restore the invariant for (pt, jn) after the move the plan describes (helper waves).  A Both step computes its new
+// row first and its new column second; the one cell they share, (pt+2, jn+2), comes out identical from both.
 template <int W, typename RT>
 __device__ __forceinline__ void otw_costs_advance(OtwLds<W, RT> &S, const OtwEnv &e, int pt, int jn, bool do_row,
                                                   bool do_col, int hidx, int hn) {
     const int c = e.c;
-    const int lim = (e.live_len < e.live_cap) ? e.live_len : e.live_cap;
-    if (do_row) otw_cost_row<W, RT>(S, e, pt + 2, jn - c + 1, jn + 1, S.Dr[(pt + 2) & 1], hidx, hn);
-    if (do_col) otw_cost_col<W, RT>(S, e, jn + 2, pt - c + 1, pt + 1, S.Dc[(jn + 2) & 1], hidx, hn);
-    // single cells, on the last threads (the first ones are the busiest above)
-    if (hidx == hn - 1 && pt + 1 < lim && jn + 1 < e.N) {  // (pt+1, jn+1): kept row pt+1 and kept column jn+1 both grow
-        const double d = otw_cost_cell<W, RT>(S, e, pt + 1, jn + 1);
-        S.Dr[(pt + 1) & 1][swz<W>(jn + 1)] = d;
-        S.Dc[(jn + 1) & 1][swz<W>(pt + 1)] = d;
-    }
-    if (hidx == hn - 2) {
-        if (do_row && !do_col) {  // kept column jn+2 gains row pt+1
-            if (pt + 1 < lim && jn + 2 < e.N) S.Dc[(jn + 2) & 1][swz<W>(pt + 1)] = otw_cost_cell<W, RT>(S, e, pt + 1, jn + 2);
-        } else if (do_col && !do_row) {  // kept row pt+2 gains column jn+1
-            if (pt + 2 < lim && jn + 1 < e.N) S.Dr[(pt + 2) & 1][swz<W>(jn + 1)] = otw_cost_cell<W, RT>(S, e, pt + 2, jn + 1);
-        }
-    }
+    // new row pt+2: its cells in columns jn+1, jn+2 are what the two column buffers lack (row pt+2); in a Both step
+    // column jn+2 is new as well and covers that cell itself
+    if (do_row) otw_cost_row<W, RT>(S, e, pt + 2, jn - c + 1, jn + 2, jn + 1, hidx, hn);
+    // new column jn+2: its cells in rows pt+1, pt+2 are what the two row buffers lack (column jn+2)
+    if (do_col) otw_cost_col<W, RT>(S, e, jn + 2, pt - c + 1, pt + 2, pt + 1, hidx, hn);
 }
 
 // A speculative strip (during the step that leaves the state at (pt, jn)): the strip the next Row-only step (row
@@ -899,10 +905,12 @@ __device__ __forceinline__ OtwSettled otw_settle_hit(double *R, double *C, const
         if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
         k.pend_dir = -2;
     }
+    // four independent LDS reads, one wait
+    const double prev_raw = band[swz<W>(pos - (n > 0 ? 1 : 0))];
     const double d = rfl(ex->d);
     const double smin = rfl(ex->min);
     const int sidx = __builtin_amdgcn_readfirstlane(ex->idx);
-    const double prev = (n > 0) ? rfl(band[swz<W>(pos - 1)]) : ((k1 > 0) ? sentinel : inf);
+    const double prev = (n > 0) ? rfl(prev_raw) : ((k1 > 0) ? sentinel : inf);
     // row hit: cell (pt, j0), "side" = up; column hit: cell (pt, jn), "side" = left -- in the chain's order
     // min(min(side + d, diag + 2d), previous cell of the strip + d)
     const double side = k.cA + d;
@@ -1072,9 +1080,11 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         }
         __syncthreads();
     }
-    if (wave == 0) {
+    if (wave == (SPEC ? HW0 : 0)) {  // the wave that will refill the rings starts its first prefetch
         otw_prefetch_live(k, e);
         otw_prefetch_ref(k, e);
+    }
+    if (wave == 0) {
         if (k.first) {
             double lf[kF], rf[kF];
 #pragma unroll
@@ -1127,13 +1137,16 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     __syncthreads();
     // prime the cost buffers for the first step (all threads), then publish its plan
     int buf = 0;
+    OtwPlan pl;  // pipelined kernel, wave 0: the plan it published, kept in registers
+    pl.t = pl.j0 = 0;
+    pl.flags = kPlanExit;
     if constexpr (SPEC) {
         otw_costs_prime<W, RT>(S, e, S.t, S.j, tid, NT);
         if (wave == 0) {
             k.cA = rfl(S.R[swz<W>(k.j)]);
             k.cU = (k.t > 0) ? rfl(S.C[swz<W>(k.t - 1)]) : inf;
             k.cL = (k.j > 0) ? rfl(S.R[swz<W>(k.j - 1)]) : inf;
-            otw_make_plan<W, RT>(S, k, e, true);
+            pl = otw_make_plan<W, RT>(S, k, e, true);
         }
     } else {
         otw_precompute<W, RT>(S, e, S.t, S.j, S.Dr[0], S.Dc[0], tid, NT);
@@ -1160,6 +1173,9 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 if (pflags & kPlanExit) break;
                 const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
                 RTS_LW_BEGIN();
+                // rings: frames the *next* step's cost work can reach (rows <= pt+3, columns <= jn+3); what this step
+                // reads was made sure of one step ago, and the slots written now are not among it (W >= c + 12)
+                if (wave == HW0) otw_refill<W, RT>(S, k, e, pt + 3, j0 + (do_col ? 1 : 0) + 3);
                 if (!(pflags & kPlanHit)) __syncthreads();  // this step's chains have read their cost buffers
                 if (!(pflags & kPlanStop))
                     otw_costs_advance<W, RT>(S, e, pt, j0 + (do_col ? 1 : 0), do_row, do_col, tid - 64 * HW0, NHELP);
@@ -1207,8 +1223,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             // (0 end-of-step barrier wait, 1 chains, 2 mid-step barrier wait, 3 settle, 4 decide, 5 plan); 6 / 14 = counts
             for (;;) {
                 RTS_STAMP2(0);
-                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]),
-                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[sp]);
+                const int pt = pl.t, j0 = pl.j0, pflags = pl.flags;  // wave 0 wrote the plan itself
                 if (pflags & kPlanExit) break;
                 const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
                 const bool stop = (pflags & kPlanStop) != 0;
@@ -1249,7 +1264,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 }
                 RTS_STAMP2(4);
                 k.spec_valid = !o.stop;  // the shadows being computed during this step belong to (k.t, k.j)
-                otw_make_plan<W, RT>(S, k, e, true, sp ^ 1);
+                pl = otw_make_plan<W, RT>(S, k, e, true, sp ^ 1);
                 RTS_STAMP2(5);
 #if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 2
                 {
@@ -1469,7 +1484,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         long long *dbg = a.debug + (size_t)e.b * 16;
         dbg[0] = lw_hit, dbg[1] = lb_hit, dbg[2] = ln_hit, dbg[3] = lw_oth, dbg[4] = lb_oth, dbg[5] = ln_oth;
     }
-    if (a.debug && lane == 0 && wave >= 1 && wave <= 4) a.debug[(size_t)e.b * 16 + 5 + wave] = lo_work;
+    if (a.debug && lane == 0 && wave >= 1 && wave <= 7) a.debug[(size_t)e.b * 16 + 5 + wave] = lo_work;
 #endif
     if (tid == 0) {
         st[RTS_ST_T] = k.t;

@@ -65,8 +65,8 @@ def main():
                 n = max(d[:, base + 2].sum(), 1)
                 print("%s: %d  wave-0 work %.0f cycles, end-of-step barrier wait %.0f cycles" % (label, n, d[:, base].sum() / n, d[:, base + 1].sum() / n))
             n = max(d[:, 2].sum(), 1)
-            print("hit steps, own work: wave 1 (row speculation) %.0f, wave 2 (column speculation) %.0f, wave 3 %.0f, wave 4 %.0f (helpers)"
-                  % tuple(d[:, 6 + i].sum() / n for i in range(4)))
+            print("hit steps, own work: wave 1 (row speculation) %.0f, wave 2 (column speculation) %.0f, helper waves 3-7: %s"
+                  % (d[:, 6].sum() / n, d[:, 7].sum() / n, ", ".join("%.0f" % (d[:, 8 + i].sum() / n) for i in range(5))))
             return
         nm = ["barrier-2 wait", "phase A (chain / install)", "barrier-1 wait", "settle", "decide", "plan + refill"]
         for base, label in ((0, "hit steps"), (8, "other steps")):
