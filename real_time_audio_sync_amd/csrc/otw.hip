@@ -86,6 +86,7 @@ struct OtwLds {
 struct OtwSpecOut {
     double min;  // np.argmin of the shadow strip
     double d;    // cost of the strip's last cell (the one the shadow leaves out)
+    double d2;   // column speculation only: cost of the corner (t+1, j+1) a Both step would add
     int idx;
     int pad;
 };
@@ -609,12 +610,13 @@ __device__ __forceinline__ OtwPlan otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, co
     }
     if ((flags & kPlanCol) && k.j + 1 >= e.N) flags |= kPlanStop;  // otw_eran.py:67-71
     if (spec) {
-        if (k.spec_valid && (flags == kPlanRow || flags == kPlanCol)) {  // the shadow becomes the band
+        // the shadow becomes the band: any Row-only / Column-only step, and a Both step while both of its strips
+        // still start at 0 like the speculated ones (otw_settle_hit_both)
+        const bool both_ok = flags == (kPlanRow | kPlanCol) && k.t <= e.c - 2 && k.j <= e.c - 2;
+        if (k.spec_valid && (flags == kPlanRow || flags == kPlanCol || both_ok)) {
             flags |= kPlanHit;
-            if (flags & kPlanRow)
-                k.ri ^= 1;
-            else
-                k.ci ^= 1;
+            if (flags & kPlanRow) k.ri ^= 1;
+            if (flags & kPlanCol) k.ci ^= 1;
         }
         flags |= (k.ri ? kPlanRi : 0) | (k.ci ? kPlanCi : 0);
     }
@@ -877,13 +879,86 @@ __device__ __forceinline__ void otw_spec_strip(const double *Dv, const double *b
     double fm;
     int fi;
     const double d_last = Dv[swz<W>(pos)];
+    const double d_next = Dv[swz<W>(pos + 1)];  // meaningful for the column strip: cost of (pt+1, jn+1)
     strip_chain<W, false, true>(Dv, band, shadow, k1, pos - k1, (k1 > 0) ? sentinel : (double)INFINITY, lane, k1, fm, fi,
                                 nullptr, nullptr, 0);
     if (lane == 0) {
         out->min = fm;
         out->idx = fi;
         out->d = d_last;
+        out->d2 = d_next;
     }
+}
+
+// The last cell of a shadow strip, in the chain's own order: min(min(side + d, diag + 2d), previous cell + d).  `side`
+// is the old band's slot at `pos` (up for a row strip, left for a column strip), `diag` its slot at pos-1.
+template <int W>
+__device__ __forceinline__ double otw_last_cell(const double *band, int pos, int c, double side_v, double diag_v, double d,
+                                                double sentinel) {
+    const double inf = INFINITY;
+    const int k1 = (pos - c + 1 > 0) ? pos - c + 1 : 0;
+    const int n = pos - k1;
+    const double prev_raw = band[swz<W>(pos - (n > 0 ? 1 : 0))];
+    const double prev = (n > 0) ? prev_raw : ((k1 > 0) ? sentinel : inf);
+    const double diag = (pos > 0) ? diag_v + 2 * d : inf;
+    return vmin(vmin(side_v + d, diag), prev + d);
+}
+
+// A Both step as a hit (wave 0).  While the band is still filling (t, j <= c-2: both strips start at 0, exactly like
+// the speculated ones) the row strip of a Both step is the row shadow plus its last cell a = (pt, j0), the column strip
+// the column shadow plus its last cell b = (pt-1, jn), and the corner follows from a, b and acc[pt-1][j0].  Waves 1 and
+// 2 need a / b as input of the next speculation and compute them for themselves (same expression, same bits).
+template <int W, typename RT>
+__device__ __forceinline__ OtwSettled otw_settle_hit_both(double *R, double *C, const OtwSpecOut *exr, const OtwSpecOut *exc,
+                                                          OtwCtl &k, const OtwEnv &e, int pt, int j0, double sentinel) {
+    const int c = e.c, lane = e.lane;
+    const int jn = j0 + 1, t0 = pt - 1;
+    if (e.deferred_update && k.pend_dir != -2) {  // livenote_v2.py:149-155
+        k.run_count = (k.pend_dir == k.prev) ? k.run_count + 1 : 1;
+        if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
+        k.pend_dir = -2;
+    }
+    const double d1 = rfl(exr->d), d2 = rfl(exc->d), d3 = rfl(exc->d2);
+    double rmin = rfl(exr->min), cmin = rfl(exc->min);
+    int ridx = __builtin_amdgcn_readfirstlane(exr->idx), cidx = __builtin_amdgcn_readfirstlane(exc->idx);
+    const double a = rfl(otw_last_cell<W>(R, j0, c, k.cA, k.cL, d1, sentinel));
+    const double b = rfl(otw_last_cell<W>(C, t0, c, k.cA, k.cU, d2, sentinel));
+    const double pa = k.cA + 2 * d3;  // acc[pt-1][j0] + 2 d(pt, jn)
+    const double av = vmin(a + d3, pa);
+    const double cl = vmin(av, b + d3);
+    if (lane == 0) {
+        R[swz<W>(j0)] = a;
+        C[swz<W>(t0)] = b;
+        R[swz<W>(jn)] = cl;
+        C[swz<W>(pt)] = cl;
+    }
+    // the strips' last cells sit at the highest index: they win only if strictly smaller (np.argmin)
+    if (a < rmin) {
+        rmin = a;
+        ridx = j0;
+    }
+    if (b < cmin) {
+        cmin = b;
+        cidx = t0;
+    }
+    const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0;
+    k.rows += 1;
+    k.cols += 1;
+    k.consumed = pt + 1;
+    k.cells += (j0 - k1r + 1) + (pt - k1c + 1);
+    k.cU = b;
+    k.cL = a;
+    k.cA = cl;
+    OtwSettled o;
+    o.row_fresh = o.col_fresh = true;
+    o.rf_min = rmin;
+    o.rf_idx = ridx;
+    o.cf_min = cmin;
+    o.cf_idx = cidx;
+    o.row_corner = o.col_corner = true;
+    o.rc = o.cc = cl;
+    o.stop = false;
+    return o;
 }
 
 // A *hit* step (wave 0): this Row-only / Column-only step's strip, all cells but the last, is the shadow that the plan
@@ -1197,6 +1272,13 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                                                     j0 + 1, true, sentinel);
                     __syncthreads();
                 }
+                if ((pflags & (kPlanHit | kPlanRow | kPlanCol)) == (kPlanHit | kPlanRow | kPlanCol)) {
+                    // Both step as a hit: the row's last cell (pt, j0) is input of the next speculation; wave 0 writes
+                    // the same value.  Its predecessors sit in the old band, which is this wave's output buffer.
+                    const double av = otw_last_cell<W>(R, j0, c, Rsh[swz<W>(j0)], Rsh[swz<W>(j0 > 0 ? j0 - 1 : 0)],
+                                                       SP.row[sp].d, sentinel);
+                    if (lane == 0) R[swz<W>(j0)] = av;
+                }
                 if (!(pflags & kPlanStop) && pt + 1 < live_len && pt + 1 < a.live_cap)  // row pt+1 over [.., jn-1]
                     otw_spec_strip<W>(S.Dr[(pt + 1) & 1], R, Rsh, jn, c, lane, sentinel, &SP.row[sp ^ 1]);
                 RTS_LW_END(pflags & kPlanHit);
@@ -1212,6 +1294,13 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 double *C = (pflags & kPlanCi) ? SP.ShC : S.C, *Csh = (pflags & kPlanCi) ? S.C : SP.ShC;
                 RTS_LW_BEGIN();
                 if (!(pflags & kPlanHit)) __syncthreads();
+                if ((pflags & (kPlanHit | kPlanRow | kPlanCol)) == (kPlanHit | kPlanRow | kPlanCol)) {
+                    // Both step as a hit: the column's last cell (pt-1, jn), as on wave 1
+                    const int t0 = pt - 1;
+                    const double bv = otw_last_cell<W>(C, t0, c, Csh[swz<W>(t0)], Csh[swz<W>(t0 > 0 ? t0 - 1 : 0)],
+                                                       SP.col[sp].d, sentinel);
+                    if (lane == 0) C[swz<W>(t0)] = bv;
+                }
                 if (!(pflags & kPlanStop) && jn + 1 < N)  // column jn+1 over rows [.., pt-1]
                     otw_spec_strip<W>(S.Dc[(jn + 1) & 1], C, Csh, pt, c, lane, sentinel, &SP.col[sp ^ 1]);
                 RTS_LW_END(pflags & kPlanHit);
@@ -1234,7 +1323,9 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 stamp_base = (pflags & kPlanHit) ? 0 : 8;
                 if (stamp_base) stamp_sum[14] += 1; else stamp_sum[6] += 1;
 #endif
-                if (pflags & kPlanHit) {
+                if ((pflags & kPlanHit) && do_row && do_col) {
+                    o = otw_settle_hit_both<W, RT>(R, C, &SP.row[sp], &SP.col[sp], k, e, pt, j0, sentinel);
+                } else if (pflags & kPlanHit) {
                     o = otw_settle_hit<W, RT>(R, C, do_row ? &SP.row[sp] : &SP.col[sp], k, e, pt, j0, do_row, sentinel);
                 } else {
                     double rf_min = inf;
