@@ -229,7 +229,8 @@ __device__ __forceinline__ double wave_min(double x) {
 template <int W, bool DENSE, bool GUARD = false>
 __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const double *band, double *band_out, int k1,
                                             int n, double x_in, int lane, int lo_arg, double &fmin_out, int &fidx_out,
-                                            double *dense_acc, double *dense_cost, long long dense_stride) {
+                                            double *dense_acc, double *dense_cost, long long dense_stride,
+                                            long long *rounds_acc = nullptr) {
     constexpr int L = W / 64;
     constexpr int LOG_L = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : 3;
     const double inf = INFINITY;
@@ -278,6 +279,7 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
         // (monotonicity), so if that holds in every lane the strip is final
         q = q + D[0];
         if (!__any(q < v[0])) break;
+        if (rounds_acc) *rounds_acc += 1;  // diagnostic builds only
         v[0] = vmin(v[0], q);
 #pragma unroll
         for (int m = 1; m < L; m++) {
@@ -874,14 +876,14 @@ __device__ __forceinline__ void otw_costs_advance(OtwLds<W, RT> &S, const OtwEnv
 // finish that step: the strip's argmin and the cost of the cell left out.
 template <int W>
 __device__ __forceinline__ void otw_spec_strip(const double *Dv, const double *band, double *shadow, int pos, int c,
-                                               int lane, double sentinel, OtwSpecOut *out) {
+                                               int lane, double sentinel, OtwSpecOut *out, long long *rounds_acc = nullptr) {
     const int k1 = (pos - c + 1 > 0) ? pos - c + 1 : 0;
     double fm;
     int fi;
     const double d_last = Dv[swz<W>(pos)];
     const double d_next = Dv[swz<W>(pos + 1)];  // meaningful for the column strip: cost of (pt+1, jn+1)
     strip_chain<W, false, true>(Dv, band, shadow, k1, pos - k1, (k1 > 0) ? sentinel : (double)INFINITY, lane, k1, fm, fi,
-                                nullptr, nullptr, 0);
+                                nullptr, nullptr, 0, rounds_acc);
     if (lane == 0) {
         out->min = fm;
         out->idx = fi;
@@ -1035,10 +1037,13 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
 #endif
 #if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 2
     long long lw_hit = 0, lb_hit = 0, lw_oth = 0, lb_oth = 0, ln_hit = 0, ln_oth = 0, l_last = 0;
-    long long lo_work = 0, lo_t0 = 0;  // waves 1, 2, 3: own work in hit steps
+    long long lo_work = 0, lo_t0 = 0;  // waves 1..7: own work in hit steps
+    long long lo_rounds = 0;           // waves 1, 2: extra carry rounds of their speculative chains
+#define RTS_ROUNDS_ACC (&lo_rounds)
 #define RTS_LW_BEGIN() do { lo_t0 = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
 #define RTS_LW_END(hit) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); if (hit) lo_work += t_ - lo_t0; } while (0)
 #else
+#define RTS_ROUNDS_ACC nullptr
 #define RTS_LW_BEGIN() do { } while (0)
 #define RTS_LW_END(hit) do { } while (0)
 #endif
@@ -1280,7 +1285,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                     if (lane == 0) R[swz<W>(j0)] = av;
                 }
                 if (!(pflags & kPlanStop) && pt + 1 < live_len && pt + 1 < a.live_cap)  // row pt+1 over [.., jn-1]
-                    otw_spec_strip<W>(S.Dr[(pt + 1) & 1], R, Rsh, jn, c, lane, sentinel, &SP.row[sp ^ 1]);
+                    otw_spec_strip<W>(S.Dr[(pt + 1) & 1], R, Rsh, jn, c, lane, sentinel, &SP.row[sp ^ 1], RTS_ROUNDS_ACC);
                 RTS_LW_END(pflags & kPlanHit);
                 __syncthreads();
                 sp ^= 1;
@@ -1302,7 +1307,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                     if (lane == 0) C[swz<W>(t0)] = bv;
                 }
                 if (!(pflags & kPlanStop) && jn + 1 < N)  // column jn+1 over rows [.., pt-1]
-                    otw_spec_strip<W>(S.Dc[(jn + 1) & 1], C, Csh, pt, c, lane, sentinel, &SP.col[sp ^ 1]);
+                    otw_spec_strip<W>(S.Dc[(jn + 1) & 1], C, Csh, pt, c, lane, sentinel, &SP.col[sp ^ 1], RTS_ROUNDS_ACC);
                 RTS_LW_END(pflags & kPlanHit);
                 __syncthreads();
                 sp ^= 1;
@@ -1576,6 +1581,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         dbg[0] = lw_hit, dbg[1] = lb_hit, dbg[2] = ln_hit, dbg[3] = lw_oth, dbg[4] = lb_oth, dbg[5] = ln_oth;
     }
     if (a.debug && lane == 0 && wave >= 1 && wave <= 7) a.debug[(size_t)e.b * 16 + 5 + wave] = lo_work;
+    if (a.debug && lane == 0 && wave >= 1 && wave <= 2) a.debug[(size_t)e.b * 16 + 12 + wave] = lo_rounds;
 #endif
     if (tid == 0) {
         st[RTS_ST_T] = k.t;

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Run on the GPU box: the round's measurement set for the headline workload.
+
+    python3 tools/collect_profile.py TAG        -> gpurun_out/profile_TAG/
+
+  1. bench.py (default flags)                                   -> TAG_bench_final.json
+  2. rocprofv3 --kernel-trace --stats -- python3 bench.py ...   -> TAG_otw_kernel_stats.csv, TAG_bench_under_rocprof.json
+  3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes, --no-cpu, 3 steps)
+                                                                -> TAG_pmc.json, otw_traffic.json
+Every profiler pass is its own child process with the program right after `--` (no shell, no env wrapper).
+Copy what should be judged from gpurun_out/profile_TAG/ into profiles/.
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "otw_advance_kernel"
+
+
+def run(cmd, out_path=None, timeout=600):
+    print("+", " ".join(cmd), flush=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout[-2000:] + "\n" + p.stderr[-4000:] + "\n")
+        raise SystemExit("command failed: %s" % " ".join(cmd))
+    if out_path:
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        with open(out_path, "w") as f:
+            f.write(line + "\n")
+        return json.loads(line)
+    return None
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not hits:
+        raise SystemExit("no *%s under %s" % (suffix, d))
+    return hits[0]
+
+
+def pmc_pass(out, name, counters):
+    d = os.path.join(out, "pmc_" + name)
+    run(["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--",
+         "python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu"])
+    sums, calls = {}, {}
+    with open(find(d, "counter_collection.csv")) as f:
+        for row in csv.DictReader(f):
+            if KERNEL not in row["Kernel_Name"]:
+                continue
+            c = row["Counter_Name"]
+            sums[c] = sums.get(c, 0.0) + float(row["Counter_Value"])
+            calls.setdefault(c, set()).add(row["Dispatch_Id"])
+    return {c: sums[c] / len(calls[c]) for c in sums}, {c: len(calls[c]) for c in sums}
+
+
+def main():
+    tag = sys.argv[1]
+    out = os.path.join(ROOT, "gpurun_out", "profile_" + tag)
+    os.makedirs(out, exist_ok=True)
+    final = run(["python3", "bench.py"], os.path.join(out, tag + "_bench_final.json"))
+    print("bench: %.3f ms/step, %.3e frames/s" % (final["ms_per_step"], final["value"]), flush=True)
+
+    d = os.path.join(out, "trace")
+    under = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--",
+                 "python3", "bench.py", "--steps", "20", "--warmup", "3"],
+                os.path.join(out, tag + "_bench_under_rocprof.json"))
+    stats = find(d, "kernel_stats.csv")
+    with open(stats) as f, open(os.path.join(out, tag + "_otw_kernel_stats.csv"), "w") as g:
+        for i, line in enumerate(f):
+            if i < 8:
+                g.write(line[:600] + ("\n" if len(line) > 600 else ""))
+    with open(stats) as f:
+        krow = [r for r in csv.DictReader(f) if KERNEL in r["Name"]][0]
+    print("rocprofv3: %s calls=%s avg=%.3f ms (bench under rocprof, HIP events: %.3f ms)"
+          % (krow["Name"][:60], krow["Calls"], float(krow["AverageNs"]) / 1e6, under["roofline"]["launch_ms"]), flush=True)
+
+    pmc, n = {}, {}
+    for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+                           ("sq1", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"]),
+                           ("sq2", ["SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT"])):
+        v, c = pmc_pass(out, name, counters)
+        pmc.update(v)
+        n.update(c)
+    summary = {"kernel": krow["Name"], "kernel_trace": {k: krow[k] for k in ("Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")},
+               "pmc_mean_per_dispatch": pmc, "pmc_dispatches": n,
+               "bench_final": {k: final[k] for k in ("value", "ms_per_step")},
+               "bench_under_rocprof_launch_ms": under["roofline"]["launch_ms"]}
+    with open(os.path.join(out, tag + "_pmc.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    traffic = {
+        "hbm_bytes_per_launch": int((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024),
+        "FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"],
+        "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024  -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per "
+                   "128-B request); this kernel's reads are 4-8 B per lane, an uncalibrated width, so the true figure lies "
+                   "between the undoubled and the doubled sum",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 3 --warmup 1 --no-cpu, "
+                  "kernel %s, %s (tools/collect_profile.py)" % (krow["Name"], tag)}
+    with open(os.path.join(out, "otw_traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+    print(json.dumps(summary["pmc_mean_per_dispatch"], indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,8 @@ def main():
             n = max(d[:, 2].sum(), 1)
             print("hit steps, own work: wave 1 (row speculation) %.0f, wave 2 (column speculation) %.0f, helper waves 3-7: %s"
                   % (d[:, 6].sum() / n, d[:, 7].sum() / n, ", ".join("%.0f" % (d[:, 8 + i].sum() / n) for i in range(5))))
+            steps = max(d[:, 2].sum() + d[:, 5].sum(), 1)
+            print("extra carry rounds per speculative chain: row %.2f, column %.2f" % (d[:, 13].sum() / steps, d[:, 14].sum() / steps))
             return
         nm = ["barrier-2 wait", "phase A (chain / install)", "barrier-1 wait", "settle", "decide", "plan + refill"]
         for base, label in ((0, "hit steps"), (8, "other steps")):
