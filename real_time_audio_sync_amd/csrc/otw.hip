@@ -1315,6 +1315,10 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         } else {
             // wave 0.  Diagnostic stamps: slots 0..5 = hit steps, 8..13 = other steps
             // (0 end-of-step barrier wait, 1 chains, 2 mid-step barrier wait, 3 settle, 4 decide, 5 plan); 6 / 14 = counts
+#if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 2
+            l_last = (long long)__builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
             for (;;) {
                 RTS_STAMP2(0);
                 const int pt = pl.t, j0 = pl.j0, pflags = pl.flags;  // wave 0 wrote the plan itself

@@ -82,6 +82,47 @@ def test_wave_count_does_not_change_results(gpu, otw_golden, waves):
         eng.close()
 
 
+@pytest.mark.parametrize("spec", ["0", "1"])
+def test_plain_and_pipelined_kernels_agree(gpu, otw_golden, monkeypatch, spec):
+    """The library picks the pipelined kernel (speculative strips, hit steps) while every stream can have a CU of its
+    own and the plain one beyond; RTS_OTW_SPEC forces either.  Both must reproduce the goldens and the oracle."""
+    monkeypatch.setenv("RTS_OTW_SPEC", spec)
+    g = otw_golden
+    ob, synth, oracle = gpu["ob"], gpu["synth"], gpu["oracle"]
+    for cid in ("A_otw_c50_insert", "B_otw_c500_insert", "D_otw_tie_c10_insert", "C_livenote_v2_euclid_c50_insert",
+                "F_otw_stop_c20_insert", "E_otw_overflow_c10_insert", "A_livenote_v2_c10_set_live"):
+        case = parse_case([m for m in g["cases"] if str(m).split("|")[0] == cid][0])
+        ref = g[case["group"] + "/ref"].astype(np.float64)
+        live = g[case["group"] + "/live"].astype(np.float64)
+        eng = ob.BatchedOTW(ref, case["c"], case["mrc"], batch=1, variant=case["variant"], euclid=case["euclid"],
+                            dtype=torch.float64)
+        lv, ln = eng.pack([live])
+        eng.run(lv, ln, mode=case["mode"])
+        _check_against_golden(g, case, eng)
+        eng.close()
+    # band widths that use the 256- and 512-cell windows, past the warm-up, ragged batch
+    for c, n_ref in ((200, 500), (500, 700)):
+        ref, lives = synth.synth_batch(n_ref, 5, seed=900 + c)
+        lives[2] = lives[2][:, :c + 37]
+        eng = ob.BatchedOTW(ref, c, 3, batch=5, dtype=torch.float32)
+        lv, ln = eng.pack(lives)
+        eng.run(lv, ln)
+        for b, live in enumerate(lives):
+            o = oracle.OtwOracle(ref, c, 3)
+            n = o.run(live)
+            st, so = eng.state(b), o.state
+            assert np.array_equal(eng.path(b), o.path), (spec, c, b)
+            for k in ("t", "j", "direction", "previous", "run_count", "status"):
+                assert st[k] == so[k], (spec, c, b, k)
+            assert st["consumed"] == n
+            cnt = o.counters
+            assert (st["cells"], st["row_strips"], st["col_strips"]) == (cnt["cells"], cnt["row_strips"], cnt["col_strips"])
+            rb, cb = eng.bands(b)
+            orb, ocb = o.bands()
+            assert np.array_equal(rb, orb, equal_nan=True) and np.array_equal(cb, ocb, equal_nan=True), (spec, c, b)
+        eng.close()
+
+
 def test_batch_vs_oracle_c500(gpu):
     """Config-3 shaped, scaled down so the dense oracle stays small: 16 different warps of one
     reference, c=500, past the warm-up."""
