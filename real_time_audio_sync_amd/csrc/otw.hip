@@ -26,6 +26,7 @@
 // accumulated costs are bit-identical to the CPU restatement, not merely close.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,8 +57,9 @@ struct OtwArgs {
 };
 
 // RT = element type of the feature rings: double, or float when both inputs are float32 (their values
-// widen back exactly, so results are identical while the workgroup's LDS drops from 131 KB to 74 KB at
-// W = 512 and two workgroups share a CU -- what matters beyond 256 concurrent streams).
+// widen back exactly, so results are identical while the plain kernel's LDS drops from 131 KB to 74 KB at
+// W = 512 -- 58 KB for the pipelined kernel, which keeps no reference ring -- and two workgroups share a CU:
+// what matters beyond 256 concurrent streams).
 template <int W, typename RT>
 struct OtwLds {
     static constexpr int L = W / 64;     // cells per lane in the chain phase
@@ -66,7 +68,6 @@ struct OtwLds {
     double C[SWZ];      // acc[.][j]  column band
     double Dr[2][SWZ];  // row strip cell costs: [buf] = this step's, [buf^1] = being pre-computed for the next
     double Dc[2][SWZ];
-    RT refw[kF][W];   // feature-major ring of reference frames (index y & (W-1))
     RT livew[kF][W];  // feature-major ring of live frames      (index x & (W-1))
     // column chain wave -> wave 0, read back in one go
     double cfresh_min;
@@ -77,6 +78,10 @@ struct OtwLds {
     // steps have no barrier between the other waves' read of a plan and wave 0's write of the next one.
     int plan_t[2], plan_j0[2], plan_flags[2];
     int t, j;                         // final position, published at exit for the epilogue
+    // feature-major ring of reference frames (index y & (W-1)).  Last member: the pipelined kernel reads the
+    // reference -- shared by all streams, L2-resident -- straight from global memory in its helper waves and
+    // allocates the struct only up to here (58 KB instead of 82 KB at W = 512 with float32 features).
+    RT refw[kF][W];
 };
 
 // Extra LDS of the pipelined kernel (SPEC).  The row band lives in R or ShR and the column band in C or ShC
@@ -579,11 +584,14 @@ __device__ __forceinline__ void otw_decide(const double *R, const double *C, Otw
 
 // Plan for the next step from the current register state (wave 0); lane 0 publishes it.
 template <int W, typename RT>
-__device__ __forceinline__ void otw_refill(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, int need_live, int need_ref) {
+__device__ __forceinline__ void otw_refill(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e, int need_live, int need_ref,
+                                           bool with_ref = true) {
     const int need_l = (need_live < e.live_len - 1) ? need_live : e.live_len - 1;
-    const int need_r = (need_ref < e.N - 1) ? need_ref : e.N - 1;
     if (need_l > k.live_hi) otw_commit_live<W, RT>(S, k, e);
-    if (need_r > k.ref_hi) otw_commit_ref<W, RT>(S, k, e);
+    if (with_ref) {
+        const int need_r = (need_ref < e.N - 1) ? need_ref : e.N - 1;
+        if (need_r > k.ref_hi) otw_commit_ref<W, RT>(S, k, e);
+    }
 }
 
 struct OtwPlan {
@@ -776,6 +784,29 @@ __device__ __forceinline__ void otw_finish(OtwLds<W, RT> &S, OtwCtl &k, const Ot
     otw_make_plan<W, RT>(S, k, e, spec);
 }
 
+// The 12 features of reference frame q, from global memory (frame-major [N][12]: 48 or 96 contiguous bytes).
+__device__ __forceinline__ void otw_ref_frame(const OtwEnv &e, int q, double (&rf)[kF]) {
+    if (e.ref_f64) {
+        const double2 *p = reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(e.ref) + (size_t)q * kF);
+#pragma unroll
+        for (int i = 0; i < kF / 2; i++) {
+            const double2 v = p[i];
+            rf[2 * i] = v.x;
+            rf[2 * i + 1] = v.y;
+        }
+    } else {
+        const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(e.ref) + (size_t)q * kF);
+#pragma unroll
+        for (int i = 0; i < kF / 4; i++) {
+            const float4 v = p[i];
+            rf[4 * i] = (double)v.x;
+            rf[4 * i + 1] = (double)v.y;
+            rf[4 * i + 2] = (double)v.z;
+            rf[4 * i + 3] = (double)v.w;
+        }
+    }
+}
+
 // ---- pipelined kernel ---------------------------------------------------------------------------------------------
 // Cost buffers are keyed by row / column parity instead of by step: Dr[r & 1] holds the costs of live row r and
 // Dc[q & 1] those of reference column q, at ring positions by column / row index.  Invariant at the start of the step
@@ -801,11 +832,8 @@ __device__ __forceinline__ void otw_cost_row(OtwLds<W, RT> &S, const OtwEnv &e, 
         const int kb = ka + hn;
         const int kb_c = (kb <= k_hi) ? kb : ka;
         double ra[kF], rb[kF];
-#pragma unroll
-        for (int f = 0; f < kF; f++) {
-            ra[f] = (double)S.refw[f][ka & (W - 1)];
-            rb[f] = (double)S.refw[f][kb_c & (W - 1)];
-        }
+        otw_ref_frame(e, ka, ra);
+        otw_ref_frame(e, kb_c, rb);
         const double da = cell_cost(lf, ra, e.euclid), db = cell_cost(lf, rb, e.euclid);
         Drow[swz<W>(ka)] = da;
         if (ka >= dual_lo) S.Dc[ka & 1][swz<W>(r)] = da;  // kept column ka gains row r
@@ -825,8 +853,7 @@ __device__ __forceinline__ void otw_cost_col(OtwLds<W, RT> &S, const OtwEnv &e, 
     if (r_lo + hidx > r_hi) return;
     double *Dcol = S.Dc[q & 1];
     double rf[kF];
-#pragma unroll
-    for (int f = 0; f < kF; f++) rf[f] = (double)S.refw[f][q & (W - 1)];
+    otw_ref_frame(e, q, rf);
     for (int ra_ = r_lo + hidx; ra_ <= r_hi; ra_ += 2 * hn) {
         const int rb_ = ra_ + hn;
         const int rb_c = (rb_ <= r_hi) ? rb_ : ra_;
@@ -1049,7 +1076,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
 #endif
     extern __shared__ __align__(16) unsigned char smem_raw[];
     OtwLds<W, RT> &S = *reinterpret_cast<OtwLds<W, RT> *>(smem_raw);
-    constexpr size_t kSpecOff = (sizeof(OtwLds<W, RT>) + 15) & ~(size_t)15;
+    using LdsT = OtwLds<W, RT>;
+    constexpr size_t kSpecOff = (offsetof(LdsT, refw) + 15) & ~(size_t)15;  // SPEC: no reference ring
     OtwSpecLds<W> &SP = *reinterpret_cast<OtwSpecLds<W> *>(smem_raw + kSpecOff);  // only touched when SPEC
 
     const int tid = threadIdx.x;
@@ -1146,9 +1174,11 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             const int fr = lo_l + idx / kF, f = idx % kF;
             S.livew[f][fr & (W - 1)] = (RT)otw_load_feat(a.live, a.live_f64, e.live_base + (long long)fr * kF + f);
         }
-        for (int idx = tid; idx < (k.ref_hi - lo_r + 1) * kF; idx += NT) {
-            const int fr = lo_r + idx / kF, f = idx % kF;
-            S.refw[f][fr & (W - 1)] = (RT)otw_load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
+        if (!SPEC) {
+            for (int idx = tid; idx < (k.ref_hi - lo_r + 1) * kF; idx += NT) {
+                const int fr = lo_r + idx / kF, f = idx % kF;
+                S.refw[f][fr & (W - 1)] = (RT)otw_load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
+            }
         }
         if (!k.first) {
             const double *bb = a.bands + (size_t)e.b * 2 * (c + 1);
@@ -1162,16 +1192,14 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     }
     if (wave == (SPEC ? HW0 : 0)) {  // the wave that will refill the rings starts its first prefetch
         otw_prefetch_live(k, e);
-        otw_prefetch_ref(k, e);
+        if (!SPEC) otw_prefetch_ref(k, e);
     }
     if (wave == 0) {
         if (k.first) {
             double lf[kF], rf[kF];
 #pragma unroll
-            for (int f = 0; f < kF; f++) {
-                lf[f] = (double)S.livew[f][0];
-                rf[f] = (double)S.refw[f][0];
-            }
+            for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][0];
+            otw_ref_frame(e, 0, rf);
             const double d = rfl(cell_cost(lf, rf, e.euclid));
             if (lane == 0) {
                 S.R[swz<W>(0)] = d;
@@ -1255,7 +1283,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 RTS_LW_BEGIN();
                 // rings: frames the *next* step's cost work can reach (rows <= pt+3, columns <= jn+3); what this step
                 // reads was made sure of one step ago, and the slots written now are not among it (W >= c + 12)
-                if (wave == HW0) otw_refill<W, RT>(S, k, e, pt + 3, j0 + (do_col ? 1 : 0) + 3);
+                if (wave == HW0) otw_refill<W, RT>(S, k, e, pt + 3, 0, false);  // the reference has no ring here
                 if (!(pflags & kPlanHit)) __syncthreads();  // this step's chains have read their cost buffers
                 if (!(pflags & kPlanStop))
                     otw_costs_advance<W, RT>(S, e, pt, j0 + (do_col ? 1 : 0), do_row, do_col, tid - 64 * HW0, NHELP);
@@ -1689,7 +1717,8 @@ namespace rts {
 
 template <int W, int NW, bool DENSE, typename RT, bool SPEC>
 static int launch_advance_d(const OtwArgs &args, int B, hipStream_t s) {
-    const size_t smem = SPEC ? ((sizeof(OtwLds<W, RT>) + 15) & ~(size_t)15) + sizeof(OtwSpecLds<W>) : sizeof(OtwLds<W, RT>);
+    using LdsT = OtwLds<W, RT>;
+    const size_t smem = SPEC ? ((offsetof(LdsT, refw) + 15) & ~(size_t)15) + sizeof(OtwSpecLds<W>) : sizeof(LdsT);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
         RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&otw_advance_kernel<W, NW, DENSE, RT, SPEC>),
@@ -1797,19 +1826,11 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     while (h->W < c + 12) h->W *= 2;
     h->waves = 8;  // waves 0/1 run the chains, 2..7 pre-compute the next step's costs
     {
-        // The pipelined kernel is the faster one per stream but needs 82 KB of LDS at c = 500, one workgroup per CU;
-        // the plain kernel fits two.  So: pipelined while every stream can have a CU of its own, plain beyond that
-        // (throughput mode).  RTS_OTW_SPEC=0/1 forces either; results are identical.
+        // The pipelined kernel (58 KB of LDS at c = 500 with float32 features: two workgroups per CU, like the plain
+        // kernel) is the faster one at every batch size measured; RTS_OTW_SPEC=0 selects the plain kernel (A/B runs,
+        // tests).  Results are identical.
         const char *sp = getenv("RTS_OTW_SPEC");
-        if (sp) {
-            h->spec = atoi(sp) != 0;
-        } else {
-            int dev = 0, n_cu = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-                n_cu = 256;
-            h->spec = B <= n_cu;
-        }
+        h->spec = sp ? (atoi(sp) != 0) : 1;
     }
     h->live_cap = 2 * N;
     h->path_cap = 3 * N + 8;  // one point per decide(); decides <= row strips + column strips <= 2N + N
