@@ -138,7 +138,10 @@ int rts_otw_device_views(rts_otw *h, int32_t **path_dev, int *path_cap, int32_t 
  * written to (never-evaluated cells hold the sentinel 1e10 / +inf, resp. -1).  NULL, NULL switches it
  * off.  Resets the handle (the matrices are re-initialised on every reset / run). */
 int rts_otw_set_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *stream);
-/* Tuning knob, not semantics: waves per stream workgroup (1, 2, 4 or 8).  Results are identical. */
+/* Tuning knob, not semantics: waves per stream workgroup (1, 2, 4 or 8; default 8).  Results are identical.
+ * With 8 waves and no dense mirror the library runs its pipelined kernel (the next step's strips are computed
+ * beside this step's control work); the environment variable RTS_OTW_SPEC=0, read by rts_otw_create, selects
+ * the plain kernel instead (A/B measurements, tests). */
 int rts_otw_set_waves(rts_otw *h, int waves);
 /* Average device time of the last kernel launches is measured by the caller with HIP events on
  * `stream`; this returns the kernel's name as it appears in rocprofv3 traces. */

@@ -3,25 +3,29 @@
 // Reference semantics: /root/reference/otw_eran.py:38-239, livenote.py:37-226,
 // livenote_v2.py:43-236 (restated on the CPU, for tests only, in oracle/rtsync_oracle.c).
 //
-// Design (DESIGN.md "OTW kernel"):
+// Design:
 //   * one workgroup (NW waves) per live stream; the whole per-stream state lives in LDS for the
 //     duration of a launch: the two live accumulated-cost bands (row t over columns [j-c, j] and
-//     column j over rows [t-c, t]) and ring windows of the last W reference / live chroma frames;
-//   * a strip (<= c cells of one row or one column) is evaluated in two phases:
-//       cost phase   one thread per cell: 12-term cost d, and a = min(up + d, diag + 2d) from
-//                    the previous band -> LDS scratch;
-//       chain phase  acc_k = min(a_k, acc_{k-1} + d_k) along the strip.  This is a serial
-//                    float64 recurrence whose rounding must not change, so it is solved by
-//                    *chunked speculative carry propagation*: every lane scans its L = W/64
-//                    consecutive cells, then lanes repeatedly re-scan with the neighbour's last
-//                    value as carry-in (DPP wave shift) until no carry changes.  Because
-//                    x -> fl(x + d) and min are monotone, the fixed point is bit-identical to the
-//                    sequential scan; it is reached after (longest carry run / L) + 1 rounds
-//                    (2-7 on chroma data at c = 500, against 500 dependent steps);
-//   * in a "Both" step the row strip (wave 0) and the column strip (wave 1) run concurrently;
-//     only the corner cell depends on both and is finished by one lane;
-//   * best_point's two argmins are wave-level reductions (value min, then lowest lane holding
-//     it), direction / run-count / path logic runs on one lane.
+//     column j over rows [t-c, t]), ring windows of the last W live (and, plain kernel, reference)
+//     chroma frames, and the cost strips the helper waves prepare ahead of time;
+//   * a strip (<= c cells of one row or one column) is one wave's job (strip_chain): with the
+//     pre-computed costs d it forms a = min(up + d, diag + 2d) from the previous band and solves
+//     acc_k = min(a_k, acc_{k-1} + d_k) along the strip.  This is a serial float64 recurrence whose
+//     rounding must not change, so it is solved by *chunked speculative carry propagation*: every
+//     lane scans its L = W/64 consecutive cells, then lanes repeatedly re-scan with the neighbour's
+//     last value as carry-in (DPP wave shift) until no carry changes.  Because x -> fl(x + d) and
+//     min are monotone, the fixed point is bit-identical to the sequential scan; it is reached after
+//     (longest carry run / L) + 1 rounds (1.8 extra rounds on average at c = 500, against 500
+//     dependent steps).  The same wave reduces the strip's np.argmin while the values are in registers;
+//   * wave 0 owns the control state in registers: corner cell, best_point / direction / run-count /
+//     path logic (decide), and the plan for the next step;
+//   * plain kernel (SPEC = false): chain phase (row strip on wave 0, column strip on wave 1 in a
+//     "Both" step), barrier, control phase, barrier; helper waves compute the next step's costs meanwhile;
+//   * pipelined kernel (SPEC = true, the default): while wave 0 runs the control work of a step, waves 1
+//     and 2 already run the row / column strip the *next* step needs if it is Row-only / Column-only
+//     (minus the last cell) into shadow bands; that step is then a "hit" -- the shadow becomes the
+//     band, wave 0 finishes one cell and decides -- with a single barrier.  See the comment at the
+//     step loops.
 // All arithmetic is float64 in the oracle's operation order (build with -ffp-contract=off), so
 // accumulated costs are bit-identical to the CPU restatement, not merely close.
 #include <hip/hip_runtime.h>
@@ -51,7 +55,7 @@ struct OtwArgs {
     int ref_f64, live_f64;
     int clamp_len;            // run mode: never read past live_stride frames
     long long *debug;         // diagnostic builds only (-DRTS_OTW_STAMPS): [B][16] cycle sums
-    int spec;                 // informational: 1 when the pipelined (speculating) kernel was selected
+    int spec;                 // 1: the pipelined kernel was selected (host-side choice; the kernel does not read it)
     double *dense_acc;        // optional [B][2N][N]: the reference's dense acc_cost (otw_eran.py:27), NULL = off
     double *dense_cost;       // optional [B][2N][N]: the reference's dense cost (otw_eran.py:23)
 };
@@ -1710,7 +1714,7 @@ struct rts_otw {
     int32_t *hist_len;  // [B]
     long long *debug;   // diagnostic builds only
     double *dense_acc, *dense_cost;  // caller-owned, optional
-    int spec;           // 1: pipelined kernel (8 waves, no dense mirror); 0: chains and control back to back
+    int spec;           // 1: pipelined kernel (needs 8 waves and no dense mirror); 0: plain kernel
 };
 
 namespace rts {
@@ -1824,7 +1828,7 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     h->cost_kind = cost_kind;
     h->W = 64;
     while (h->W < c + 12) h->W *= 2;
-    h->waves = 8;  // waves 0/1 run the chains, 2..7 pre-compute the next step's costs
+    h->waves = 8;  // wave 0: control (+ chains of steps that are not hits), waves 1/2: chains, 3..7: cost strips, ring refill
     {
         // The pipelined kernel (58 KB of LDS at c = 500 with float32 features: two workgroups per CU, like the plain
         // kernel) is the faster one at every batch size measured; RTS_OTW_SPEC=0 selects the plain kernel (A/B runs,

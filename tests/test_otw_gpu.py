@@ -84,8 +84,8 @@ def test_wave_count_does_not_change_results(gpu, otw_golden, waves):
 
 @pytest.mark.parametrize("spec", ["0", "1"])
 def test_plain_and_pipelined_kernels_agree(gpu, otw_golden, monkeypatch, spec):
-    """The library picks the pipelined kernel (speculative strips, hit steps) while every stream can have a CU of its
-    own and the plain one beyond; RTS_OTW_SPEC forces either.  Both must reproduce the goldens and the oracle."""
+    """The pipelined kernel (speculative strips, hit steps) is the default; RTS_OTW_SPEC=0 selects the plain one
+    (chain phase, then control phase).  Both must reproduce the goldens and the oracle."""
     monkeypatch.setenv("RTS_OTW_SPEC", spec)
     g = otw_golden
     ob, synth, oracle = gpu["ob"], gpu["synth"], gpu["oracle"]
