@@ -162,16 +162,10 @@ __device__ __forceinline__ double vmin(double a, double b) {
     return r;
 }
 
-// lane i receives lane i-1's value; lane 0 receives `lane0`.  The s_nop covers the VALU-write ->
-// DPP-read hazard for a source produced by the preceding (asm or compiler) instruction.
+// lane i receives lane i-1's value; lane 0 receives `lane0` (DPP wave_shr:1; lanes without a source keep `old`).
 __device__ __forceinline__ double wave_shift_up(double v, double lane0) {
-    int lo = __double2loint(lane0), hi = __double2hiint(lane0);
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf"
-        : "+v"(lo), "+v"(hi)
-        : "v"(__double2loint(v)), "v"(__double2hiint(v)));
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), __double2hiint(v), 0x138, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
@@ -191,24 +185,20 @@ __device__ __forceinline__ double rfl(double v) {
 
 // Minimum over the 64 lanes, returned in every lane.  Six DPP steps (row_shr 1/2/4/8, then
 // row_bcast 15 and 31) leave the total in lane 63; lanes without a DPP source keep their own value.
-#define RTS_DPP_MIN_STEP(CTRL)                                                   \
-    do {                                                                         \
-        int tlo = __double2loint(x), thi = __double2hiint(x);                    \
-        asm volatile("s_nop 1\n\t"                                               \
-                     "v_mov_b32_dpp %0, %2 " CTRL "\n\t"                         \
-                     "v_mov_b32_dpp %1, %3 " CTRL                                \
-                     : "+v"(tlo), "+v"(thi)                                      \
-                     : "v"(__double2loint(x)), "v"(__double2hiint(x)));          \
-        x = vmin(x, __hiloint2double(thi, tlo));                                 \
+#define RTS_DPP_MIN_STEP(CTRL, ROWMASK)                                                                       \
+    do {                                                                                                      \
+        const int tlo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), CTRL, ROWMASK, 0xf, false); \
+        const int thi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), CTRL, ROWMASK, 0xf, false); \
+        x = vmin(x, __hiloint2double(thi, tlo));                                                              \
     } while (0)
 
 __device__ __forceinline__ double wave_min(double x) {
-    RTS_DPP_MIN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf");
-    RTS_DPP_MIN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
-    RTS_DPP_MIN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf");
-    RTS_DPP_MIN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf");
-    RTS_DPP_MIN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    RTS_DPP_MIN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    RTS_DPP_MIN_STEP(0x111, 0xf);  // row_shr:1
+    RTS_DPP_MIN_STEP(0x112, 0xf);  // row_shr:2
+    RTS_DPP_MIN_STEP(0x114, 0xf);  // row_shr:4
+    RTS_DPP_MIN_STEP(0x118, 0xf);  // row_shr:8
+    RTS_DPP_MIN_STEP(0x142, 0xa);  // row_bcast:15
+    RTS_DPP_MIN_STEP(0x143, 0xc);  // row_bcast:31
     return wave_bcast(x, 63);
 }
 
