@@ -6,7 +6,7 @@
 //   chroma_frames_kernel   one workgroup (256 threads) per frame, persistent over frames:
 //       1. L samples (zero-padded on the left by `pad_left`, chroma.py:49) x window -> LDS as L/2
 //          packed complex float64 (even sample = re, odd = im);
-//       2. L/2-point complex Stockham radix-2 FFT in LDS (float64; twiddles exp(-2 pi i n / L),
+//       2. L/2-point complex Stockham radix-4 (+ one radix-2 stage) FFT in LDS (float64; twiddles exp(-2 pi i n / L),
 //          n < L/2, are tabulated once per workgroup in LDS from a host-computed table);
 //       3. real-FFT untangling -> the L/2+1 rfft bins, optionally stored (create_stft's output),
 //          power spectrum -> LDS;
@@ -98,27 +98,28 @@ __device__ __forceinline__ void project_normalize(const ChromaArgs &g, const dou
             red[kCh * kChromaNT + tid] = sum;
         }
         __syncthreads();
-        if (tid == 0) {
-            double c[kCh];
+        if (tid < 64) {  // wave 0: lane p < 12 finishes bin p (same order of additions as before), lane 0 the norm
+            double cp = 0.0;
+            if (tid < kCh) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) cp = cp + red[kCh * kChromaNT + tid * 16 + q];
+            }
             double ss = 0.0;
 #pragma unroll
             for (int p = 0; p < kCh; p++) {
-                double sum = 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; q++) sum = sum + red[kCh * kChromaNT + p * 16 + q];
-                c[p] = sum;
-                const double sq = c[p] * c[p];
+                const double c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cp), p),
+                                                  __builtin_amdgcn_readlane(__double2loint(cp), p));
+                const double sq = c * c;
                 ss = ss + sq;
             }
             double len = sqrt(ss);
             if (!g.normalize || len < 2.2250738585072014e-308) len = 1.0;  // librosa.util.normalize, fill=None
-#pragma unroll
-            for (int p = 0; p < kCh; p++) {
-                const double v = c[p] / len;
+            if (tid < kCh) {
+                const double v = cp / len;
                 if (g.out_f64)
-                    reinterpret_cast<double *>(g.chroma_out)[(size_t)(frame0 + f) * kCh + p] = v;
+                    reinterpret_cast<double *>(g.chroma_out)[(size_t)(frame0 + f) * kCh + tid] = v;
                 else
-                    reinterpret_cast<float *>(g.chroma_out)[(size_t)(frame0 + f) * kCh + p] = (float)v;
+                    reinterpret_cast<float *>(g.chroma_out)[(size_t)(frame0 + f) * kCh + tid] = (float)v;
             }
         }
         __syncthreads();
@@ -153,13 +154,26 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
                                  : (void *)(reinterpret_cast<float *>(g.chroma_out) + oo);
     }
 
+    // this thread's window coefficients (sample pairs n = tid + r*256) stay in registers for every frame
+    constexpr int kMaxPairs = 8;  // N2/256 <= 8 for L <= 4096
+    double win_re[kMaxPairs], win_im[kMaxPairs];
+#pragma unroll
+    for (int r = 0; r < kMaxPairs; r++) {
+        const int n = tid + r * kChromaNT;
+        win_re[r] = (n < N2) ? g.window[2 * n] : 0.0;
+        win_im[r] = (n < N2) ? g.window[2 * n + 1] : 0.0;
+    }
+
     for (int frame0 = blockIdx.x * kChromaFR; frame0 < g.n_frames; frame0 += gridDim.x * kChromaFR) {
         const int nf = (g.n_frames - frame0 < kChromaFR) ? g.n_frames - frame0 : kChromaFR;
         for (int f = 0; f < nf; f++) {
             const int frame = frame0 + f;
             // 1. load + window, packed as complex
             const long long s0 = g.frame_offset + (long long)frame * g.hop;
-            for (int n = tid; n < N2; n += kChromaNT) {
+#pragma unroll
+            for (int r = 0; r < kMaxPairs; r++) {
+                const int n = tid + r * kChromaNT;
+                if (n >= N2) break;
                 const long long s = s0 + 2 * n;
                 double x0 = 0.0, x1 = 0.0;
                 if (s >= 0 && s < g.n_samples)
@@ -168,26 +182,25 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
                 if (s + 1 >= 0 && s + 1 < g.n_samples)
                     x1 = g.samples_f64 ? reinterpret_cast<const double *>(g.samples)[s + 1]
                                        : (double)reinterpret_cast<const float *>(g.samples)[s + 1];
-                z[n] = make_double2(x0 * g.window[2 * n], x1 * g.window[2 * n + 1]);
+                z[n] = make_double2(x0 * win_re[r], x1 * win_im[r]);
             }
             __syncthreads();
-            // 2. Stockham radix-2, N2 points, in place via registers (read all, barrier, write all)
-            const int half = N2 / 2;
-            constexpr int kMaxBf = 4;  // butterflies per thread per stage (N2/2/256 <= 4 for L <= 4096)
-            for (int p = 1; p < N2; p <<= 1) {
+            // 2. Stockham autosort FFT, N2 points, in place via registers (read all, barrier, write all): one radix-2
+            //    stage when log2(N2) is odd, then radix-4 stages -- 6 stages / 12 barriers for L = 4096 instead of 11 / 22
+            //    and half the LDS traffic.  Stage with sub-transform length p: butterfly i = s*p + k reads i + m*N2/r
+            //    (m < r), twiddles exp(-2 pi i k m / (r p)) = tw[k m N2 / (r p / 2)], writes s*(r p) + k + m*p.
+            int p = 1;
+            if ((31 - __clz(N2)) & 1) {  // log2(N2) odd
+                const int half = N2 / 2;
+                constexpr int kMaxBf = 4;  // N2/2/256 <= 4 for L <= 4096
                 double2 o0[kMaxBf], o1[kMaxBf];
-                int jj[kMaxBf];
-                const int tstride = N2 / p;  // exp(-2 pi i k / (2p)) = tw[k * N2 / p]
 #pragma unroll
                 for (int r = 0; r < kMaxBf; r++) {
                     const int i = tid + r * kChromaNT;
                     if (i < half) {
-                        const int k = i & (p - 1);
-                        const double2 u0 = z[i];
-                        const double2 u1 = cmul(tw[k * tstride], z[i + half]);
+                        const double2 u0 = z[i], u1 = z[i + half];  // p = 1: k = 0, twiddle 1
                         o0[r] = make_double2(u0.x + u1.x, u0.y + u1.y);
                         o1[r] = make_double2(u0.x - u1.x, u0.y - u1.y);
-                        jj[r] = ((i - k) << 1) + k;
                     }
                 }
                 __syncthreads();
@@ -195,8 +208,52 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
                 for (int r = 0; r < kMaxBf; r++) {
                     const int i = tid + r * kChromaNT;
                     if (i < half) {
-                        z[jj[r]] = o0[r];
-                        z[jj[r] + p] = o1[r];
+                        z[2 * i] = o0[r];
+                        z[2 * i + 1] = o1[r];
+                    }
+                }
+                __syncthreads();
+                p = 2;
+            }
+            const int q = N2 / 4;
+            for (; p < N2; p <<= 2) {
+                constexpr int kMaxBf4 = 2;  // N2/4/256 <= 2 for L <= 4096
+                double2 o[kMaxBf4][4];
+                int jj[kMaxBf4];
+                const int tstep = N2 / (2 * p);
+#pragma unroll
+                for (int r = 0; r < kMaxBf4; r++) {
+                    const int i = tid + r * kChromaNT;
+                    if (i < q) {
+                        const int k = i & (p - 1);
+                        const int t1 = k * tstep, t2 = 2 * t1, t3 = 3 * t1;  // t1 < N2/2, t2 < N2, t3 < 3 N2/2
+                        const double2 w1 = tw[t1], w2 = tw[t2];
+                        double2 w3 = tw[t3 & (N2 - 1)];
+                        if (t3 >= N2) w3 = make_double2(-w3.x, -w3.y);  // exp(-i (pi + x)) = -exp(-i x)
+                        const double2 u0 = z[i];
+                        const double2 u1 = cmul(w1, z[i + q]);
+                        const double2 u2 = cmul(w2, z[i + 2 * q]);
+                        const double2 u3 = cmul(w3, z[i + 3 * q]);
+                        const double2 a0 = make_double2(u0.x + u2.x, u0.y + u2.y);
+                        const double2 a1 = make_double2(u0.x - u2.x, u0.y - u2.y);
+                        const double2 a2 = make_double2(u1.x + u3.x, u1.y + u3.y);
+                        const double2 a3 = make_double2(u1.y - u3.y, -(u1.x - u3.x));  // -i (u1 - u3)
+                        o[r][0] = make_double2(a0.x + a2.x, a0.y + a2.y);
+                        o[r][1] = make_double2(a1.x + a3.x, a1.y + a3.y);
+                        o[r][2] = make_double2(a0.x - a2.x, a0.y - a2.y);
+                        o[r][3] = make_double2(a1.x - a3.x, a1.y - a3.y);
+                        jj[r] = ((i - k) << 2) + k;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kMaxBf4; r++) {
+                    const int i = tid + r * kChromaNT;
+                    if (i < q) {
+                        z[jj[r]] = o[r][0];
+                        z[jj[r] + p] = o[r][1];
+                        z[jj[r] + 2 * p] = o[r][2];
+                        z[jj[r] + 3 * p] = o[r][3];
                     }
                 }
                 __syncthreads();
