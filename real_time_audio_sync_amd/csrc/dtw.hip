@@ -64,27 +64,25 @@ __global__ void __launch_bounds__(NT) dtw_dp_kernel(DtwArgs g) {
     double *acc = g.acc + base;
     int8_t *back = g.back + base;
 
-    // rows handled by this thread: i = tid + r*NT.  The register prefetch covers r < kPf rows;
-    // any further rows (M > kPf*NT) read their cost directly.
-    constexpr int kPf = 4;
-    double pre[kPf];
+    // rows handled by this thread: i = tid + r*NT.  The register prefetch covers r < kPf rows and runs two
+    // diagonals ahead (one diagonal is well under a microsecond of work, a cost read from HBM/L2 takes longer); the
+    // three register sets rotate by name (the loop is unrolled by three), so no copy forces an early wait.  Any
+    // further rows (M > kPf*NT) read their cost directly.
+    constexpr int kPf = (NT >= 1024) ? 2 : 4;  // 1024 threads leave 128 registers each: three sets of two
+    double ca[kPf], cb[kPf], cc[kPf];
+    auto fetch = [&](double (&dst)[kPf], int dd) {
 #pragma unroll
-    for (int r = 0; r < kPf; r++) {
-        const int i = tid + r * NT;
-        pre[r] = (i < M && i == 0) ? cost[0] : 0.0;  // diagonal 0 holds only cell (0,0)
-    }
+        for (int r = 0; r < kPf; r++) {
+            const int i = tid + r * NT;
+            const int j = dd - i;
+            dst[r] = (i < M && j >= 0 && j < N) ? cost[(size_t)i * N + j] : 0.0;
+        }
+    };
     const int n_diag = M + N - 1;
-    for (int d = 0; d < n_diag; d++) {
+    auto step = [&](const double (&pre)[kPf], int d) {
         double *cur = diag + (size_t)(d % 3) * M;
         const double *p1 = diag + (size_t)((d + 2) % 3) * M;  // diagonal d-1
         const double *p2 = diag + (size_t)((d + 1) % 3) * M;  // diagonal d-2
-        double nxt[kPf];
-#pragma unroll
-        for (int r = 0; r < kPf; r++) {  // prefetch diagonal d+1
-            const int i = tid + r * NT;
-            const int j = d + 1 - i;
-            nxt[r] = (i < M && j >= 0 && j < N) ? cost[(size_t)i * N + j] : 0.0;
-        }
         for (int r = 0, i = tid; i < M; r++, i += NT) {
             const int j = d - i;
             if (j < 0 || j >= N) continue;
@@ -126,10 +124,28 @@ __global__ void __launch_bounds__(NT) dtw_dp_kernel(DtwArgs g) {
             acc[(size_t)i * N + j] = best;
             back[(size_t)i * N + j] = (int8_t)s;
         }
-#pragma unroll
-        for (int r = 0; r < kPf; r++) pre[r] = nxt[r];
-        __syncthreads();
+        // the diagonals are the only cross-thread traffic: LDS-only barrier when they live in LDS, so that the acc /
+        // back-pointer stores of this diagonal stay in flight
+        if (g.diag_ws)
+            __syncthreads();
+        else
+            lds_barrier();
+    };
+    fetch(ca, 0);
+    fetch(cb, 1);
+    for (int d = 0; d < n_diag; d += 3) {
+        fetch(cc, d + 2);
+        step(ca, d);
+        if (d + 1 < n_diag) {
+            fetch(ca, d + 3);
+            step(cb, d + 1);
+        }
+        if (d + 2 < n_diag) {
+            fetch(cb, d + 4);
+            step(cc, d + 2);
+        }
     }
+    __syncthreads();  // back-pointers visible to the lane that walks them
 
     // ---- backtrack (dtw.py:43-52)
     __shared__ int s_len;

@@ -66,12 +66,13 @@ __device__ __forceinline__ double wtw_dot_strided(const double *x, const double 
     return t1 + t2;
 }
 
-__global__ void __launch_bounds__(1024) wtw_advance_kernel(WtwArgs g) {
+template <bool BIG>  // BIG: window state in the HBM workspace (W > kWtwLdsW), 1024 threads; else LDS, 256 threads
+__global__ void __launch_bounds__(BIG ? 1024 : 256) wtw_advance_kernel(WtwArgs g) {
     extern __shared__ __align__(16) unsigned char wtw_smem[];
     const int W = g.W;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int kWtwNT = blockDim.x;  // 256 for LDS-resident windows, 1024 for HBM-resident ones
-    const bool big = W > kWtwLdsW;
+    constexpr int kWtwNT = BIG ? 1024 : 256;  // = blockDim.x
+    constexpr bool big = BIG;
     double *xs_l = reinterpret_cast<double *>(wtw_smem);  // [W][F] live window   (LDS-resident case)
     double *ys_l = xs_l + (size_t)(big ? 0 : W) * kWF;    // [W][F] ref window
     double *nx = big ? g.ws + (size_t)b * 5 * W : ys_l + (size_t)W * kWF;  // [W]
@@ -174,8 +175,12 @@ __global__ void __launch_bounds__(1024) wtw_advance_kernel(WtwArgs g) {
                     Bm[(size_t)i * W + j] = code;
                     if (g.dlast) g.dlast[((size_t)b * W + i) * W + j] = dv;
                 }
-                __syncthreads();
+                if (big)
+                    __syncthreads();
+                else
+                    lds_barrier();  // diagonals in LDS: leave the back-pointer / D stores in flight
             }
+            __syncthreads();  // back-pointers (HBM for W > 128) visible to the lane that walks them
             if (tid == 0) {
                 // find_path (wtw.py:219-240): walk back from (n-1, m-1); sub[] holds it reversed
                 int i = n - 1, j = m - 1, len = 0;
@@ -325,7 +330,7 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         (big && (e = hipMalloc((void **)&h->ws, sizeof(double) * 5 * (size_t)W * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->ws_sub, sizeof(int32_t) * 4 * (size_t)W * B)) != hipSuccess) ||
         (keep_last_d && (e = hipMalloc((void **)&h->dlast, sizeof(double) * (size_t)B * W * W)) != hipSuccess) ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) {
         rts_wtw_destroy(h);
         return set_error(RTS_ERR_HIP, "WTW allocation failed: %s", hipGetErrorString(e));
@@ -396,7 +401,10 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.W = h->W;
     g.hopf = h->hopf;
     g.path_cap = h->path_cap;
-    hipLaunchKernelGGL(wtw_advance_kernel, dim3(h->B), dim3(h->W > kWtwLdsW ? 1024 : kWtwNT), h->smem, s, g);
+    if (h->W > kWtwLdsW)
+        hipLaunchKernelGGL(wtw_advance_kernel<true>, dim3(h->B), dim3(1024), h->smem, s, g);
+    else
+        hipLaunchKernelGGL(wtw_advance_kernel<false>, dim3(h->B), dim3(kWtwNT), h->smem, s, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
