@@ -718,17 +718,23 @@ __device__ __forceinline__ OtwSettled otw_settle(OtwLds<W, RT> &S, double *R, do
     }
     double cl = 0.0, cf_min = inf;
     int cf_idx = 0x7fffffff;
+    // everything this phase reads from LDS, issued back to back (one round trip instead of six; values a step kind
+    // does not use are read anyway and ignored)
+    const int ncc = nc - (do_row ? 1 : 0);
+    const double ld_row_last = R[swz<W>(j0)];
+    const double ld_col_last = C[swz<W>(k1c + (ncc > 0 ? ncc - 1 : 0))];
+    const double ld_cf_min = S.cfresh_min, ld_corner_d = S.corner_d, ld_corner_pa = S.corner_pa;
+    const int ld_cf_idx = S.cfresh_idx;
     // last cell of the row strip = acc[t][j0]; of the column chain = acc[t-1][jn] (Both) or acc[t][jn]
-    const double row_last = do_row ? rfl(R[swz<W>(j0)]) : 0.0;
+    const double row_last = do_row ? rfl(ld_row_last) : 0.0;
     if (do_row && !col_active && lane == 0) C[swz<W>(pt)] = row_last;  // column j0 gains row t
     if (col_active) {
-        const int ncc = nc - (do_row ? 1 : 0);
-        cl = (ncc > 0) ? rfl(C[swz<W>(k1c + ncc - 1)]) : ((k1c > 0) ? sentinel : inf);
-        cf_min = rfl(S.cfresh_min);
-        cf_idx = __builtin_amdgcn_readfirstlane(S.cfresh_idx);
+        cl = (ncc > 0) ? rfl(ld_col_last) : ((k1c > 0) ? sentinel : inf);
+        cf_min = rfl(ld_cf_min);
+        cf_idx = __builtin_amdgcn_readfirstlane(ld_cf_idx);
         if (do_row) {
-            const double d = rfl(S.corner_d);
-            const double av = vmin(row_last + d, rfl(S.corner_pa));
+            const double d = rfl(ld_corner_d);
+            const double av = vmin(row_last + d, rfl(ld_corner_pa));
             cl = vmin(av, cl + d);  // cl was the value of (t-1, jn), or the sentinel carry
             if (lane == 0) {
                 C[swz<W>(pt)] = cl;
@@ -1368,11 +1374,13 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                     RTS_STAMP(9);
                     __syncthreads();
                     RTS_STAMP(10);
+                    // the three band slots the next hit step's last cell depends on: acc[pt][jn] is what settle() is about
+                    // to write, the other two are not touched by it and are read in the same round trip as its inputs
+                    const double ld_u = C[swz<W>(pt > 0 ? pt - 1 : 0)], ld_l = R[swz<W>(jn > 0 ? jn - 1 : 0)];
                     o = otw_settle<W, DENSE, RT>(S, R, C, k, a, e, pt, j0, pflags, rf_min, rf_idx, sentinel);
-                    // the three band slots the next hit step's last cell depends on (reads follow this wave's own writes)
-                    k.cA = rfl(R[swz<W>(jn)]);
-                    k.cU = (pt > 0) ? rfl(C[swz<W>(pt - 1)]) : inf;
-                    k.cL = (jn > 0) ? rfl(R[swz<W>(jn - 1)]) : inf;
+                    k.cA = o.cc;
+                    k.cU = (pt > 0) ? rfl(ld_u) : inf;
+                    k.cL = (jn > 0) ? rfl(ld_l) : inf;
                 }
                 RTS_STAMP2(3);
                 if (o.stop) {
