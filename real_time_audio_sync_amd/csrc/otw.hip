@@ -97,7 +97,7 @@ struct OtwSpecOut {
     double d;    // cost of the strip's last cell (the one the shadow leaves out)
     double d2;   // column speculation only: cost of the corner (t+1, j+1) a Both step would add
     int idx;
-    int pad;
+    int flag;    // column speculation: 1 if dropping the strip's first cell leaves every other cell unchanged
 };
 template <int W>
 struct alignas(16) OtwSpecLds {
@@ -225,11 +225,12 @@ __device__ __forceinline__ double wave_min(double x) {
 // corner slot, which the fix-up rewrites; every band position is written with its real value
 // before it is ever read (rows/columns only grow at the top index).  Valid cells are always finite:
 // each has a computed predecessor in the previous row (row strip) or column (column strip).
-template <int W, bool DENSE, bool GUARD = false>
+template <int W, bool DENSE, bool GUARD = false, bool ALT = false>
 __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const double *band, double *band_out, int k1,
                                             int n, double x_in, int lane, int lo_arg, double &fmin_out, int &fidx_out,
                                             double *dense_acc, double *dense_cost, long long dense_stride,
-                                            long long *rounds_acc = nullptr) {
+                                            long long *rounds_acc = nullptr, bool prev0_xin = false, double alt_xin = 0.0,
+                                            int *alt_ok = nullptr) {
     constexpr int L = W / 64;
     constexpr int LOG_L = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : 3;
     const double inf = INFINITY;
@@ -256,16 +257,25 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
 #pragma unroll
     for (int m = 0; m < L; m++) D[m] = Dv[slot[m + 1]];
     prevb[0] = (k1 == 0 && lane == 0) ? inf : prevb[0];  // row/column 0 has no diagonal predecessor
+    // speculative strips only: position k1-1 is being rewritten with the sentinel by wave 0 in this very step
+    if (GUARD && ALT) prevb[0] = (prev0_xin && lane == 0) ? x_in : prevb[0];
 #pragma unroll
     for (int m = 0; m < L; m++) D[m] = (m < nloc) ? D[m] : inf;
     // round 0: every lane scans its own cells; only lane 0 knows its true carry-in
     double p = (lane == 0) ? x_in : inf;
+    double am1 = inf;  // kept for the alt_ok test below
 #pragma unroll
     for (int m = 0; m < L; m++) {
         const double am = vmin(prevb[m + 1] + D[m], prevb[m] + 2 * D[m]);
+        if (GUARD && ALT && m == 1) am1 = am;
         p = p + D[m];
         v[m] = vmin(am, p);
         p = v[m];
+    }
+    if (GUARD && ALT && L >= 2) {
+        // Would the strip that starts one cell later -- carry-in alt_xin at cell 1 instead of cell 0's value -- be the
+        // same from cell 1 on?  Lane 0's cells are final after round 0, and cell 1's value decides everything after it.
+        if (alt_ok) *alt_ok = __builtin_amdgcn_readfirstlane((int)(vmin(am1, alt_xin + D[1]) == v[1]));
     }
     // further rounds: carry-in = left neighbour's current last value.  Values only ever decrease
     // and min(A, chain of rounded adds from the carry) is exactly what the serial scan computes
@@ -399,6 +409,9 @@ struct OtwEnv {  // launch-invariant values every helper needs
 constexpr int kPlanRow = 1, kPlanCol = 2, kPlanStop = 4, kPlanExit = 8;
 constexpr int kPlanHit = 16;  // pipelined kernel: this Row-only / Column-only step's strip already sits in its shadow
 constexpr int kPlanRi = 32, kPlanCi = 64;  // pipelined kernel: buffer holding the row / column band in this step
+// pipelined kernel: a Both step with a full band that is a hit if the column speculation says so (its flag is only
+// known after the barrier, so every wave resolves this bit at the top of the step: otw_resolve_plan)
+constexpr int kPlanHitIf = 128;
 
 __device__ __forceinline__ double otw_load_feat(const void *base, int is_f64, long long idx) {
     return is_f64 ? reinterpret_cast<const double *>(base)[idx] : (double)reinterpret_cast<const float *>(base)[idx];
@@ -616,11 +629,16 @@ __device__ __forceinline__ OtwPlan otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, co
     if (spec) {
         // the shadow becomes the band: any Row-only / Column-only step, and a Both step while both of its strips
         // still start at 0 like the speculated ones (otw_settle_hit_both)
-        const bool both_ok = flags == (kPlanRow | kPlanCol) && k.t <= e.c - 2 && k.j <= e.c - 2;
+        const bool both = flags == (kPlanRow | kPlanCol);
+        const bool both_ok = both && k.t <= e.c - 2 && k.j <= e.c - 2;
         if (k.spec_valid && (flags == kPlanRow || flags == kPlanCol || both_ok)) {
             flags |= kPlanHit;
             if (flags & kPlanRow) k.ri ^= 1;
             if (flags & kPlanCol) k.ci ^= 1;
+        } else if (k.spec_valid && both && W >= 128 && k.t - ((k.t - e.c + 1 > 0) ? k.t - e.c + 1 : 0) >= 2) {
+            // a Both step later on: still the two speculated strips, if the column strip survives losing its first
+            // cell (otw_resolve_plan); needs two cells per lane in the chain (W >= 128) and two cells in the strip
+            flags |= kPlanHitIf;
         }
         flags |= (k.ri ? kPlanRi : 0) | (k.ci ? kPlanCi : 0);
     }
@@ -901,32 +919,34 @@ __device__ __forceinline__ void otw_costs_advance(OtwLds<W, RT> &S, const OtwEnv
 // pt+1, pos = jn) or Column-only step (column jn+1, pos = pt) would run, without its last cell `pos`, from the band --
 // whose slots below `pos` are final when the speculating wave starts -- into the shadow; plus what wave 0 needs to
 // finish that step: the strip's argmin and the cost of the cell left out.
-template <int W>
+template <int W, bool ALT>  // ALT: the column speculation (exports the flag, may be told to ignore position k1-1)
 __device__ __forceinline__ void otw_spec_strip(const double *Dv, const double *band, double *shadow, int pos, int c,
-                                               int lane, double sentinel, OtwSpecOut *out, long long *rounds_acc = nullptr) {
+                                               int lane, double sentinel, OtwSpecOut *out, long long *rounds_acc = nullptr,
+                                               bool prev0_sentinel = false) {
     const int k1 = (pos - c + 1 > 0) ? pos - c + 1 : 0;
     double fm;
     int fi;
     const double d_last = Dv[swz<W>(pos)];
     const double d_next = Dv[swz<W>(pos + 1)];  // meaningful for the column strip: cost of (pt+1, jn+1)
-    strip_chain<W, false, true>(Dv, band, shadow, k1, pos - k1, (k1 > 0) ? sentinel : (double)INFINITY, lane, k1, fm, fi,
-                                nullptr, nullptr, 0, rounds_acc);
+    int alt_ok = 0;
+    strip_chain<W, false, true, ALT>(Dv, band, shadow, k1, pos - k1, (k1 > 0) ? sentinel : (double)INFINITY, lane, k1, fm, fi,
+                                nullptr, nullptr, 0, rounds_acc, prev0_sentinel, sentinel, &alt_ok);
     if (lane == 0) {
         out->min = fm;
         out->idx = fi;
         out->d = d_last;
         out->d2 = d_next;
+        out->flag = alt_ok;
     }
 }
 
 // The last cell of a shadow strip, in the chain's own order: min(min(side + d, diag + 2d), previous cell + d).  `side`
 // is the old band's slot at `pos` (up for a row strip, left for a column strip), `diag` its slot at pos-1.
 template <int W>
-__device__ __forceinline__ double otw_last_cell(const double *band, int pos, int c, double side_v, double diag_v, double d,
+__device__ __forceinline__ double otw_last_cell(const double *band, int pos, int k1, double side_v, double diag_v, double d,
                                                 double sentinel) {
     const double inf = INFINITY;
-    const int k1 = (pos - c + 1 > 0) ? pos - c + 1 : 0;
-    const int n = pos - k1;
+    const int n = pos - k1;  // the strip is [k1, pos]
     const double prev_raw = band[swz<W>(pos - (n > 0 ? 1 : 0))];
     const double prev = (n > 0) ? prev_raw : ((k1 > 0) ? sentinel : inf);
     const double diag = (pos > 0) ? diag_v + 2 * d : inf;
@@ -950,8 +970,14 @@ __device__ __forceinline__ OtwSettled otw_settle_hit_both(double *R, double *C, 
     const double d1 = rfl(exr->d), d2 = rfl(exc->d), d3 = rfl(exc->d2);
     double rmin = rfl(exr->min), cmin = rfl(exc->min);
     int ridx = __builtin_amdgcn_readfirstlane(exr->idx), cidx = __builtin_amdgcn_readfirstlane(exc->idx);
-    const double a = rfl(otw_last_cell<W>(R, j0, c, k.cA, k.cL, d1, sentinel));
-    const double b = rfl(otw_last_cell<W>(C, t0, c, k.cA, k.cU, d2, sentinel));
+    // the Both step's strips: row pt over [k1r, j0] -- the speculated row strip plus its last cell; column jn over
+    // [k1c, pt-1] -- the speculated column strip [k1c_s, pt-2] without its first cell once the band is full
+    // (k1c = k1c_s + 1; the speculation's flag vouches that dropping it changes nothing else) plus its last cell
+    const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0;
+    const int lo_r = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // decide() looks at row pt from here on
+    const int k1c_s = (t0 - c + 1 > 0) ? t0 - c + 1 : 0;
+    const double a = rfl(otw_last_cell<W>(R, j0, k1r, k.cA, k.cL, d1, sentinel));
+    const double b = rfl(otw_last_cell<W>(C, t0, k1c, k.cA, k.cU, d2, sentinel));
     const double pa = k.cA + 2 * d3;  // acc[pt-1][j0] + 2 d(pt, jn)
     const double av = vmin(a + d3, pa);
     const double cl = vmin(av, b + d3);
@@ -960,6 +986,7 @@ __device__ __forceinline__ OtwSettled otw_settle_hit_both(double *R, double *C, 
         C[swz<W>(t0)] = b;
         R[swz<W>(jn)] = cl;
         C[swz<W>(pt)] = cl;
+        if (k1c > k1c_s) C[swz<W>(k1c - 1)] = sentinel;  // the dropped cell's slot: what the in-place strip leaves there
     }
     // the strips' last cells sit at the highest index: they win only if strictly smaller (np.argmin)
     if (a < rmin) {
@@ -970,7 +997,11 @@ __device__ __forceinline__ OtwSettled otw_settle_hit_both(double *R, double *C, 
         cmin = b;
         cidx = t0;
     }
-    const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0;
+    // a speculated argmin that sits on a cell outside the Both step's window cannot be used: let decide() reduce the
+    // band (which holds a and b by now) instead
+    const bool row_ok = ridx >= lo_r, col_ok = cidx >= k1c;
+    if (!row_ok) k.rb_idx = -1;
+    if (!col_ok) k.cb_idx = -1;
     k.rows += 1;
     k.cols += 1;
     k.consumed = pt + 1;
@@ -979,7 +1010,8 @@ __device__ __forceinline__ OtwSettled otw_settle_hit_both(double *R, double *C, 
     k.cL = a;
     k.cA = cl;
     OtwSettled o;
-    o.row_fresh = o.col_fresh = true;
+    o.row_fresh = row_ok;
+    o.col_fresh = col_ok;
     o.rf_min = rmin;
     o.rf_idx = ridx;
     o.cf_min = cmin;
@@ -988,6 +1020,17 @@ __device__ __forceinline__ OtwSettled otw_settle_hit_both(double *R, double *C, 
     o.rc = o.cc = cl;
     o.stop = false;
     return o;
+}
+
+// Pipelined kernel, every wave at the top of a step: a Both step planned "hit if the column speculation allows"
+// becomes a hit (both shadows become the bands) or stays a regular step.  The flag was exported before the barrier
+// that ended the previous step, so all waves read the same value.
+__device__ __forceinline__ int otw_resolve_plan(int pflags, int pt, int c, const OtwSpecOut *exc) {
+    if (pflags & kPlanHitIf) {
+        const bool ok = (pt < c) || __builtin_amdgcn_readfirstlane(exc->flag) != 0;  // pt < c: no cell is dropped
+        if (ok) pflags = (pflags | kPlanHit) ^ (kPlanRi | kPlanCi);
+    }
+    return pflags;
 }
 
 // A *hit* step (wave 0): this Row-only / Column-only step's strip, all cells but the last, is the shadow that the plan
@@ -1276,8 +1319,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         // either way: a speculative strip is the same chain on the same inputs, the last cell the chain's own expression.
         if (wave >= HW0) {
             for (;;) {
-                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]),
-                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[sp]);
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]);
+                const int pflags = otw_resolve_plan(__builtin_amdgcn_readfirstlane(S.plan_flags[sp]), pt, c, &SP.col[sp]);
                 if (pflags & kPlanExit) break;
                 const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
                 RTS_LW_BEGIN();
@@ -1293,8 +1336,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
             }
         } else if (wave == 1) {
             for (;;) {
-                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]),
-                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[sp]);
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]);
+                const int pflags = otw_resolve_plan(__builtin_amdgcn_readfirstlane(S.plan_flags[sp]), pt, c, &SP.col[sp]);
                 if (pflags & kPlanExit) break;
                 const int jn = j0 + ((pflags & kPlanCol) ? 1 : 0);
                 double *R = (pflags & kPlanRi) ? SP.ShR : S.R, *Rsh = (pflags & kPlanRi) ? S.R : SP.ShR;
@@ -1308,34 +1351,37 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 if ((pflags & (kPlanHit | kPlanRow | kPlanCol)) == (kPlanHit | kPlanRow | kPlanCol)) {
                     // Both step as a hit: the row's last cell (pt, j0) is input of the next speculation; wave 0 writes
                     // the same value.  Its predecessors sit in the old band, which is this wave's output buffer.
-                    const double av = otw_last_cell<W>(R, j0, c, Rsh[swz<W>(j0)], Rsh[swz<W>(j0 > 0 ? j0 - 1 : 0)],
-                                                       SP.row[sp].d, sentinel);
+                    const double av = otw_last_cell<W>(R, j0, (j0 - c + 1 > 0) ? j0 - c + 1 : 0, Rsh[swz<W>(j0)],
+                                                       Rsh[swz<W>(j0 > 0 ? j0 - 1 : 0)], SP.row[sp].d, sentinel);
                     if (lane == 0) R[swz<W>(j0)] = av;
                 }
                 if (!(pflags & kPlanStop) && pt + 1 < live_len && pt + 1 < a.live_cap)  // row pt+1 over [.., jn-1]
-                    otw_spec_strip<W>(S.Dr[(pt + 1) & 1], R, Rsh, jn, c, lane, sentinel, &SP.row[sp ^ 1], RTS_ROUNDS_ACC);
+                    otw_spec_strip<W, false>(S.Dr[(pt + 1) & 1], R, Rsh, jn, c, lane, sentinel, &SP.row[sp ^ 1], RTS_ROUNDS_ACC);
                 RTS_LW_END(pflags & kPlanHit);
                 __syncthreads();
                 sp ^= 1;
             }
         } else if (wave == 2) {
             for (;;) {
-                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]),
-                          pflags = __builtin_amdgcn_readfirstlane(S.plan_flags[sp]);
+                const int pt = __builtin_amdgcn_readfirstlane(S.plan_t[sp]), j0 = __builtin_amdgcn_readfirstlane(S.plan_j0[sp]);
+                const int pflags = otw_resolve_plan(__builtin_amdgcn_readfirstlane(S.plan_flags[sp]), pt, c, &SP.col[sp]);
                 if (pflags & kPlanExit) break;
                 const int jn = j0 + ((pflags & kPlanCol) ? 1 : 0);
                 double *C = (pflags & kPlanCi) ? SP.ShC : S.C, *Csh = (pflags & kPlanCi) ? S.C : SP.ShC;
                 RTS_LW_BEGIN();
                 if (!(pflags & kPlanHit)) __syncthreads();
+                bool drop = false;
                 if ((pflags & (kPlanHit | kPlanRow | kPlanCol)) == (kPlanHit | kPlanRow | kPlanCol)) {
                     // Both step as a hit: the column's last cell (pt-1, jn), as on wave 1
                     const int t0 = pt - 1;
-                    const double bv = otw_last_cell<W>(C, t0, c, Csh[swz<W>(t0)], Csh[swz<W>(t0 > 0 ? t0 - 1 : 0)],
-                                                       SP.col[sp].d, sentinel);
+                    // (the Both step's column strip starts at max(0, pt-c+1): one cell later than the shadow once the band is full)
+                    const double bv = otw_last_cell<W>(C, t0, (pt - c + 1 > 0) ? pt - c + 1 : 0, Csh[swz<W>(t0)],
+                                                       Csh[swz<W>(t0 > 0 ? t0 - 1 : 0)], SP.col[sp].d, sentinel);
                     if (lane == 0) C[swz<W>(t0)] = bv;
+                    drop = pt >= c;  // wave 0 is writing the sentinel into position pt-c, this strip's diagonal input
                 }
                 if (!(pflags & kPlanStop) && jn + 1 < N)  // column jn+1 over rows [.., pt-1]
-                    otw_spec_strip<W>(S.Dc[(jn + 1) & 1], C, Csh, pt, c, lane, sentinel, &SP.col[sp ^ 1], RTS_ROUNDS_ACC);
+                    otw_spec_strip<W, true>(S.Dc[(jn + 1) & 1], C, Csh, pt, c, lane, sentinel, &SP.col[sp ^ 1], RTS_ROUNDS_ACC, drop);
                 RTS_LW_END(pflags & kPlanHit);
                 __syncthreads();
                 sp ^= 1;
@@ -1349,8 +1395,13 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
 #endif
             for (;;) {
                 RTS_STAMP2(0);
-                const int pt = pl.t, j0 = pl.j0, pflags = pl.flags;  // wave 0 wrote the plan itself
+                const int pt = pl.t, j0 = pl.j0;  // wave 0 wrote the plan itself
+                const int pflags = otw_resolve_plan(pl.flags, pt, c, &SP.col[sp]);
                 if (pflags & kPlanExit) break;
+                if ((pl.flags & kPlanHitIf) && (pflags & kPlanHit)) {  // resolved to a hit: both shadows become bands
+                    k.ri ^= 1;
+                    k.ci ^= 1;
+                }
                 const bool do_row = (pflags & kPlanRow) != 0, do_col = (pflags & kPlanCol) != 0;
                 const bool stop = (pflags & kPlanStop) != 0;
                 const int jn = j0 + (do_col ? 1 : 0);
