@@ -147,31 +147,53 @@ __global__ void __launch_bounds__(NT) dtw_dp_kernel(DtwArgs g) {
     }
     __syncthreads();  // back-pointers visible to the lane that walks them
 
-    // ---- backtrack (dtw.py:43-52)
-    __shared__ int s_len;
+    // ---- backtrack (dtw.py:43-52).  One lane walks the back-pointers, but not through HBM one dependent load at a
+    // time: the workgroup stages the 64 x 64 tile whose bottom-right corner is the walk's position in LDS, the lane
+    // walks until it leaves the tile (at least 64 steps), and so on.
+    constexpr int kT = 64;
+    __shared__ int s_len, s_i, s_j;
+    __shared__ int8_t s_tile[kT][kT + 4];
     int32_t *path = g.path + (size_t)pair * (M + N) * 2;
     if (tid == 0) {
-        int i = M - 1, j = N - 1, len = 0;
-        path[0] = i;
-        path[1] = j;
-        len = 1;
-        while (i > 0 || j > 0) {
-            const int s = back[(size_t)i * N + j];
-            if (s == 0)
-                j -= 1;
-            else if (s == 1)
-                i -= 1;
-            else {
-                i -= 1;
-                j -= 1;
-            }
-            path[2 * len] = i;
-            path[2 * len + 1] = j;
-            len++;
-        }
-        s_len = len;
-        g.path_len[pair] = len;
+        path[0] = M - 1;
+        path[1] = N - 1;
+        s_len = 1;
+        s_i = M - 1;
+        s_j = N - 1;
     }
+    __syncthreads();
+    while (s_i > 0 || s_j > 0) {  // uniform: shared values only change behind barriers
+        const int i0 = s_i, j0 = s_j;
+        const int ti = (i0 - kT + 1 > 0) ? i0 - kT + 1 : 0, tj = (j0 - kT + 1 > 0) ? j0 - kT + 1 : 0;
+        const int th = i0 - ti + 1, tw = j0 - tj + 1;
+        for (int idx = tid; idx < th * tw; idx += NT) {
+            const int r = idx / tw, q = idx - r * tw;
+            s_tile[r][q] = back[(size_t)(ti + r) * N + (tj + q)];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int i = i0, j = j0, len = s_len;
+            while (i >= ti && j >= tj && (i > 0 || j > 0)) {
+                const int s = s_tile[i - ti][j - tj];
+                if (s == 0)
+                    j -= 1;
+                else if (s == 1)
+                    i -= 1;
+                else {
+                    i -= 1;
+                    j -= 1;
+                }
+                path[2 * len] = i;
+                path[2 * len + 1] = j;
+                len++;
+            }
+            s_len = len;
+            s_i = i;
+            s_j = j;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) g.path_len[pair] = s_len;
     __syncthreads();
     const int len = s_len;
     for (int p = tid; p < len / 2; p += NT) {  // path.reverse()
