@@ -50,13 +50,20 @@ __global__ void __launch_bounds__(256) dtw_cost_kernel(DtwArgs g) {
     g.cost[((size_t)pair * g.M + i) * g.N + j] = 1.0 - s;
 }
 
-template <int NT>
+// WS: the three diagonals live in an HBM workspace (long sequences) instead of LDS -- a compile-time choice so that
+// the common case addresses them with LDS instructions, not through generic (flat) pointers.
+template <int NT, bool WS>
 __global__ void __launch_bounds__(NT) dtw_dp_kernel(DtwArgs g) {
     extern __shared__ __align__(16) unsigned char dtw_smem[];
     const int pair = blockIdx.x;
     // [3][M]: LDS, or (long sequences) an HBM workspace -- workgroup-scope visibility through the barrier
     // is all a single-workgroup sweep needs
-    double *diag = g.diag_ws ? g.diag_ws + (size_t)pair * 3 * g.M : reinterpret_cast<double *>(dtw_smem);
+    auto diag_row = [&](int which) {
+        if constexpr (WS)
+            return g.diag_ws + ((size_t)pair * 3 + which) * g.M;
+        else
+            return reinterpret_cast<double *>(dtw_smem) + (size_t)which * g.M;
+    };
     const int tid = threadIdx.x;
     const int M = g.M, N = g.N;
     const size_t base = (size_t)pair * M * N;
@@ -80,9 +87,9 @@ __global__ void __launch_bounds__(NT) dtw_dp_kernel(DtwArgs g) {
     };
     const int n_diag = M + N - 1;
     auto step = [&](const double (&pre)[kPf], int d) {
-        double *cur = diag + (size_t)(d % 3) * M;
-        const double *p1 = diag + (size_t)((d + 2) % 3) * M;  // diagonal d-1
-        const double *p2 = diag + (size_t)((d + 1) % 3) * M;  // diagonal d-2
+        auto cur = diag_row(d % 3);
+        const auto p1 = diag_row((d + 2) % 3);  // diagonal d-1
+        const auto p2 = diag_row((d + 1) % 3);  // diagonal d-2
         for (int r = 0, i = tid; i < M; r++, i += NT) {
             const int j = d - i;
             if (j < 0 || j >= N) continue;
@@ -126,7 +133,7 @@ __global__ void __launch_bounds__(NT) dtw_dp_kernel(DtwArgs g) {
         }
         // the diagonals are the only cross-thread traffic: LDS-only barrier when they live in LDS, so that the acc /
         // back-pointer stores of this diagonal stay in flight
-        if (g.diag_ws)
+        if constexpr (WS)
             __syncthreads();
         else
             lds_barrier();
@@ -263,30 +270,32 @@ int rts_dtw_ws(const void *a_dev, int a_dtype, long long a_stride, const void *b
     hipLaunchKernelGGL(dtw_cost_kernel, dim3((N + 63) / 64, (M + 3) / 4, B), dim3(256), 0, s, g);
     RTS_HIP(hipGetLastError());
     // one row per thread up to 1024 rows; fewer waves for small M keeps the per-diagonal barrier cheap
-    if (M <= 256) {
+    if (!in_lds) {
+        hipLaunchKernelGGL((dtw_dp_kernel<1024, true>), dim3(B), dim3(1024), smem, s, g);
+    } else if (M <= 256) {
         static bool done = false;
         if (!done) {
-            RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_dp_kernel<256>),
+            RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_dp_kernel<256, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             done = true;
         }
-        hipLaunchKernelGGL((dtw_dp_kernel<256>), dim3(B), dim3(256), smem, s, g);
+        hipLaunchKernelGGL((dtw_dp_kernel<256, false>), dim3(B), dim3(256), smem, s, g);
     } else if (M <= 512) {
         static bool done = false;
         if (!done) {
-            RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_dp_kernel<512>),
+            RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_dp_kernel<512, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             done = true;
         }
-        hipLaunchKernelGGL((dtw_dp_kernel<512>), dim3(B), dim3(512), smem, s, g);
+        hipLaunchKernelGGL((dtw_dp_kernel<512, false>), dim3(B), dim3(512), smem, s, g);
     } else {
         static bool done = false;
         if (!done) {
-            RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_dp_kernel<1024>),
+            RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_dp_kernel<1024, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             done = true;
         }
-        hipLaunchKernelGGL((dtw_dp_kernel<1024>), dim3(B), dim3(1024), smem, s, g);
+        hipLaunchKernelGGL((dtw_dp_kernel<1024, false>), dim3(B), dim3(1024), smem, s, g);
     }
     RTS_HIP(hipGetLastError());
     return RTS_OK;
