@@ -66,7 +66,9 @@ __device__ __forceinline__ double wtw_dot_strided(const double *x, const double 
     return t1 + t2;
 }
 
-template <bool BIG>  // BIG: window state in the HBM workspace (W > kWtwLdsW), 1024 threads; else LDS, 256 threads
+// BIG: window state in the HBM workspace (W > kWtwLdsW), 1024 threads; else LDS, 256 threads.  BL: back-pointers in
+// LDS (W <= kWtwLdsB) rather than HBM.  Compile-time, so that every pointer has a known address space.
+template <bool BIG, bool BL>
 __global__ void __launch_bounds__(BIG ? 1024 : 256) wtw_advance_kernel(WtwArgs g) {
     extern __shared__ __align__(16) unsigned char wtw_smem[];
     const int W = g.W;
@@ -85,7 +87,12 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) wtw_advance_kernel(WtwArgs g
 
     int32_t *st = g.state + (size_t)b * 8;
     const double *live = g.live + (size_t)b * g.N * kWF;
-    int8_t *Bm = (W <= kWtwLdsB) ? bl : (g.bwork + (size_t)b * W * W);
+    auto Bm = [&]() {
+        if constexpr (BL)
+            return bl;
+        else
+            return g.bwork + (size_t)b * W * W;
+    }();
     // `appended` may exceed the capacity N: the excess columns were dropped by the append kernel and mean
     // "the next column does not fit" (wtw.py:92 would raise IndexError) once the stored ones are consumed
     const int appended_raw = g.appended[b];
@@ -330,7 +337,9 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         (big && (e = hipMalloc((void **)&h->ws, sizeof(double) * 5 * (size_t)W * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->ws_sub, sizeof(int32_t) * 4 * (size_t)W * B)) != hipSuccess) ||
         (keep_last_d && (e = hipMalloc((void **)&h->dlast, sizeof(double) * (size_t)B * W * W)) != hipSuccess) ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<false>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<false, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) {
         rts_wtw_destroy(h);
         return set_error(RTS_ERR_HIP, "WTW allocation failed: %s", hipGetErrorString(e));
@@ -402,9 +411,11 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.hopf = h->hopf;
     g.path_cap = h->path_cap;
     if (h->W > kWtwLdsW)
-        hipLaunchKernelGGL(wtw_advance_kernel<true>, dim3(h->B), dim3(1024), h->smem, s, g);
+        hipLaunchKernelGGL((wtw_advance_kernel<true, false>), dim3(h->B), dim3(1024), h->smem, s, g);
+    else if (h->W > kWtwLdsB)
+        hipLaunchKernelGGL((wtw_advance_kernel<false, false>), dim3(h->B), dim3(kWtwNT), h->smem, s, g);
     else
-        hipLaunchKernelGGL(wtw_advance_kernel<false>, dim3(h->B), dim3(kWtwNT), h->smem, s, g);
+        hipLaunchKernelGGL((wtw_advance_kernel<false, true>), dim3(h->B), dim3(kWtwNT), h->smem, s, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
