@@ -56,6 +56,7 @@ extern "C" {
 #define RTS_RUNNING 0
 #define RTS_STOP_REF_END 1  /* insert() returned "stop": otw_eran.py:69-71, livenote_v2.py:80-82 */
 #define RTS_LIVE_OVERFLOW 2 /* "ran out of room in pre-allocated live-sequence": otw_eran.py:53-55 */
+#define RTS_DEVICE_FAULT 3  /* an in-launch hand-off between workgroups ran into its bound (never expected) */
 
 /* how rts_otw_run walks the live sequence */
 #define RTS_MODE_INSERT_LOOP 0 /* for i: insert(live[:, i])  (tests.py:160-163, test_simple.py:122-125) */
@@ -151,25 +152,24 @@ const char *rts_otw_kernel_name(const rts_otw *h);
  * Offline DTW, batched over B independent (a, b) pairs.
  * ------------------------------------------------------------------------------------------ */
 
-/* Bytes of the int8 back-pointer workspace rts_dtw needs (B*M*N). */
-int rts_dtw_workspace_bytes(int M, int N, int B, size_t *back_bytes);
+/* Bytes of the device workspace rts_dtw needs for (M, N, B): packed step codes (2 bits per cell), the rows
+ * handed between the workgroups of one pair's pipeline, and a status word. */
+int rts_dtw_workspace_bytes(int M, int N, int B, size_t *bytes);
 
 /* Replaces dtw.DTW(seq_a, seq_b) -> (cost, acc_cost, path) (dtw.py:5-53).
  *   a_dev: [B][M][F] frames of seq_a (rows of the matrices), `a_stride` = frames between
  *          consecutive pairs (0 = every pair shares one a); b_dev / b_stride likewise, [B][N][F].
- *   cost_dev, acc_dev: double [B][M][N] outputs (dtw.py:11, :14); back_dev: int8 [B][M][N]
- *          step codes 0 = (0,-1), 1 = (-1,0), 2 = (-1,-1) (dtw.py:30); path_dev: int32
- *          [B][M+N][2], pairs (i, j) from (0,0) to (M-1,N-1); path_len_dev: int32 [B].
- * M is limited to 6400 rows here (three float64 diagonals are kept in LDS; see rts_dtw_ws).  Asynchronous on `stream`;
+ *   cost_dev, acc_dev: double [B][M][N] outputs (dtw.py:11, :14); back_dev: optional (may be NULL) int8
+ *          [B][M][N], the reference's internal `back` matrix: step codes 0 = (0,-1), 1 = (-1,0),
+ *          2 = (-1,-1) (dtw.py:30); path_dev: int32 [B][M+N][2], pairs (i, j) from (0,0) to (M-1,N-1);
+ *          path_len_dev: int32 [B] (-1 if the device pipeline reported a fault).
+ *   ws_dev / ws_bytes: caller-owned, 16-byte aligned scratch of at least rts_dtw_workspace_bytes(M, N, B).
+ * Any M, N >= 1 (a long pair is spread over many workgroups).  B <= 65535.  Asynchronous on `stream`;
  * no allocation, no synchronisation (graph-capturable). */
 int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_dev, int b_dtype,
             long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
-            int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, void *stream);
-/* The same without the 6400-row limit: `diag_ws_dev` is a caller-owned workspace of B*3*M doubles holding the
- * three rotating anti-diagonals in HBM when they do not fit LDS (ignored, may be NULL, when M <= 6400). */
-int rts_dtw_ws(const void *a_dev, int a_dtype, long long a_stride, const void *b_dev, int b_dtype,
-               long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
-               int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, double *diag_ws_dev, void *stream);
+            int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, void *ws_dev, size_t ws_bytes,
+            void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Chroma front end: frame -> window -> rFFT -> power -> 12-bin filterbank -> L2 normalise.
@@ -232,8 +232,8 @@ typedef struct rts_wtw rts_wtw;
 /* Replaces the chroma-level state of WTW.__init__ (wtw.py:50-68): `chroma_ref_dev` is the reference
  * chroma [M][F] float64 (what wtw.py:37-41 computes; use rts_chroma_frames with pad_left =
  * fft_len/2), held by reference.  win_frames = dtw_win_size / hop_size, hop_frames = dtw_hop_size /
- * hop_size (wtw.py:100,:107), 1 <= win_frames <= 16384 (LDS-resident up to 512 frames, HBM workspace
- * above), hop_frames >= 1.  The handle owns a live
+ * hop_size (wtw.py:100,:107), 1 <= win_frames <= 16384 (one workgroup per stream up to 512 frames; a
+ * pipeline of workgroups per window above), hop_frames >= 1.  The handle owns a live
  * chroma history of 2M frames per stream (wtw.py:52,:55).  keep_last_d != 0 also keeps the last
  * window's accumulated-cost matrix D for inspection (the reference stores it into self.acc_cost,
  * wtw.py:105). */

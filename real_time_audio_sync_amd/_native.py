@@ -12,7 +12,7 @@ F32, F64 = 0, 1
 VARIANT_OTW, VARIANT_LIVENOTE, VARIANT_LIVENOTE_V2 = 0, 1, 2
 COST_DOT, COST_EUCLID = 0, 1
 DIR_NONE, DIR_BOTH, DIR_ROW, DIR_COLUMN = -1, 0, 1, 2
-RUNNING, STOP_REF_END, LIVE_OVERFLOW = 0, 1, 2
+RUNNING, STOP_REF_END, LIVE_OVERFLOW, DEVICE_FAULT = 0, 1, 2, 3
 MODE_INSERT_LOOP, MODE_SET_LIVE = 0, 1
 STATE_LEN = 16
 (ST_T, ST_J, ST_DIRECTION, ST_PREVIOUS, ST_RUN_COUNT, ST_STATUS, ST_FIRST_INSERT, ST_N_PATH, ST_CONSUMED,
@@ -67,8 +67,8 @@ _decl("rts_otw_set_dense", _i32, [_vp, _vp, _vp, _vp])
 _decl("rts_otw_kernel_name", ctypes.c_char_p, [_vp])
 _i64 = ctypes.c_longlong
 _decl("rts_dtw_workspace_bytes", _i32, [_i32, _i32, _i32, ctypes.POINTER(ctypes.c_size_t)])
-_decl("rts_dtw", _i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp])
-_decl("rts_dtw_ws", _i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+_decl("rts_dtw", _i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                        ctypes.c_size_t, _vp])
 
 
 _decl("rts_chroma_num_frames", _i64, [_i64, _i32, _i32, _i32])

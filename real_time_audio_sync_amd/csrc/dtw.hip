@@ -1,20 +1,21 @@
 // Offline DTW for gfx950: dtw.DTW(seq_a, seq_b) -> (cost, acc_cost, path)   (/root/reference/dtw.py:5-53)
 //
-//   dtw_cost_kernel   cost[i][j] = 1 - <a_i, b_j>  (the only GEMM-shaped op on this path, K = 12:
-//                     far too thin for MFMA to matter; one fma chain per element in dgemm's
-//                     k-order, coalesced stores), whole chip.
-//   dtw_dp_kernel     one workgroup per (a, b) pair sweeps the anti-diagonals d = i + j.  Every
-//                     cell of a diagonal depends only on the two previous diagonals, which live in
-//                     three rotating LDS rows indexed by i; so each cell performs exactly the
-//                     reference's three float64 adds and first-minimum argmin (dtw.py:35-40) and
-//                     the result is bit-identical to the serial double loop.  The next diagonal's
-//                     costs are fetched before the barrier to hide the strided global read.
-//                     The same launch ends with the backtrack (dtw.py:43-52): one lane walks the
-//                     back-pointers, then all threads reverse the path in place.
+//   dtw_cost_kernel       cost[i][j] = 1 - <a_i, b_j>  (K = 12: far too thin for MFMA to matter; one fma
+//                         chain per element in dgemm's k-order, coalesced stores), whole chip.
+//   dtw_sdp_kernel        the accumulated-cost recurrence as a strip DP (sdp.h): a wave owns 64 rows, its
+//                         lanes are skewed in time and exchange predecessors by DPP; the waves of a
+//                         workgroup and the workgroups of a launch form one pipeline down the matrix, so a
+//                         single long pair spreads over many CUs and a batch of short pairs fills the chip.
+//                         Every cell does the reference's three float64 adds and first-minimum argmin
+//                         (dtw.py:35-40): acc_cost is bit-identical to the serial double loop.
+//   dtw_backtrack_kernel  dtw.py:43-52 over the packed step codes, one wave per pair.
+//   dtw_back_decode_kernel optional: the reference's `back` matrix as int8 [M][N].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
+#include "sdp.h"
 
 namespace rts {
 
@@ -25,12 +26,15 @@ struct DtwArgs {
     const void *b;  // [B][N][F]
     double *cost;   // [B][M][N]
     double *acc;    // [B][M][N]
-    int8_t *back;   // [B][M][N]
+    int8_t *back;   // [B][M][N] or NULL
     int32_t *path;  // [B][M+N][2]
     int32_t *path_len;  // [B]
     long long a_stride, b_stride;
     int M, N, a_f64, b_f64;
-    double *diag_ws;  // [B][3][M] doubles in HBM when the three diagonals do not fit LDS, else NULL
+    uint32_t *codes;           // [B][codes_words]
+    unsigned long long *bnd;   // [B][n_strips][N]
+    int32_t *err;
+    int n_rg;
 };
 
 __device__ __forceinline__ double dtw_load(const void *p, int f64, long long idx) {
@@ -50,160 +54,36 @@ __global__ void __launch_bounds__(256) dtw_cost_kernel(DtwArgs g) {
     g.cost[((size_t)pair * g.M + i) * g.N + j] = 1.0 - s;
 }
 
-// WS: the three diagonals live in an HBM workspace (long sequences) instead of LDS -- a compile-time choice so that
-// the common case addresses them with LDS instructions, not through generic (flat) pointers.
-template <int NT, bool WS>
-__global__ void __launch_bounds__(NT) dtw_dp_kernel(DtwArgs g) {
+__global__ void __launch_bounds__(512) dtw_sdp_kernel(DtwArgs g) {
     extern __shared__ __align__(16) unsigned char dtw_smem[];
-    const int pair = blockIdx.x;
-    // [3][M]: LDS, or (long sequences) an HBM workspace -- workgroup-scope visibility through the barrier
-    // is all a single-workgroup sweep needs
-    auto diag_row = [&](int which) {
-        if constexpr (WS)
-            return g.diag_ws + ((size_t)pair * 3 + which) * g.M;
-        else
-            return reinterpret_cast<double *>(dtw_smem) + (size_t)which * g.M;
-    };
-    const int tid = threadIdx.x;
+    const int pair = blockIdx.y;
+    const int NW = blockDim.x >> 6;
+    sdp::Problem pb;
+    pb.x = g.a_f64 ? (const void *)(reinterpret_cast<const double *>(g.a) + (long long)pair * g.a_stride * kDtwF)
+                   : (const void *)(reinterpret_cast<const float *>(g.a) + (long long)pair * g.a_stride * kDtwF);
+    pb.y = g.b_f64 ? (const void *)(reinterpret_cast<const double *>(g.b) + (long long)pair * g.b_stride * kDtwF)
+                   : (const void *)(reinterpret_cast<const float *>(g.b) + (long long)pair * g.b_stride * kDtwF);
+    pb.x_f64 = g.a_f64;
+    pb.y_f64 = g.b_f64;
+    pb.M = g.M;
+    pb.N = g.N;
+    pb.D = g.acc + (size_t)pair * g.M * g.N;
+    pb.ldD = g.N;
+    pb.codes = g.codes + (size_t)pair * sdp::codes_words(g.M, g.N);
+    pb.bnd = g.bnd + (size_t)pair * sdp::n_strips(g.M) * g.N;
+    pb.err = g.err;
+    for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x) sdp::run_rowgroup<sdp::DtwPolicy, true>(pb, rg, g.n_rg, NW, dtw_smem);
+}
+
+__global__ void __launch_bounds__(64) dtw_backtrack_kernel(DtwArgs g) {
+    __shared__ uint32_t win[sdp::kBtChunks * 64];
+    const int pair = blockIdx.x, lane = threadIdx.x;
     const int M = g.M, N = g.N;
-    const size_t base = (size_t)pair * M * N;
-    const double *cost = g.cost + base;
-    double *acc = g.acc + base;
-    int8_t *back = g.back + base;
-
-    // rows handled by this thread: i = tid + r*NT.  The register prefetch covers r < kPf rows and runs two
-    // diagonals ahead (one diagonal is well under a microsecond of work, a cost read from HBM/L2 takes longer); the
-    // three register sets rotate by name (the loop is unrolled by three), so no copy forces an early wait.  Any
-    // further rows (M > kPf*NT) read their cost directly.
-    constexpr int kPf = (NT >= 1024) ? 2 : 4;  // 1024 threads leave 128 registers each: three sets of two
-    double ca[kPf], cb[kPf], cc[kPf];
-    auto fetch = [&](double (&dst)[kPf], int dd) {
-#pragma unroll
-        for (int r = 0; r < kPf; r++) {
-            const int i = tid + r * NT;
-            const int j = dd - i;
-            dst[r] = (i < M && j >= 0 && j < N) ? cost[(size_t)i * N + j] : 0.0;
-        }
-    };
-    const int n_diag = M + N - 1;
-    auto step = [&](const double (&pre)[kPf], int d) {
-        auto cur = diag_row(d % 3);
-        const auto p1 = diag_row((d + 2) % 3);  // diagonal d-1
-        const auto p2 = diag_row((d + 1) % 3);  // diagonal d-2
-        for (int r = 0, i = tid; i < M; r++, i += NT) {
-            const int j = d - i;
-            if (j < 0 || j >= N) continue;
-            double c;
-            if (r < kPf) {
-                c = pre[0];
-#pragma unroll
-                for (int q = 1; q < kPf; q++) c = (r == q) ? pre[q] : c;
-            } else {
-                c = cost[(size_t)i * N + j];
-            }
-            double best;
-            int s;
-            if (i == 0 && j == 0) {
-                best = c;
-                s = 2;  // dtw.py:20-21
-            } else if (j == 0) {
-                best = c + p1[i - 1];  // dtw.py:24
-                s = 1;
-            } else if (i == 0) {
-                best = c + p1[0];  // dtw.py:27
-                s = 0;
-            } else {
-                const double o0 = p1[i] + c;          // (i, j-1)
-                const double o1 = p1[i - 1] + c;      // (i-1, j)
-                const double o2 = p2[i - 1] + 2 * c;  // (i-1, j-1)
-                best = o0;
-                s = 0;
-                if (o1 < best) {
-                    best = o1;
-                    s = 1;
-                }
-                if (o2 < best) {
-                    best = o2;
-                    s = 2;
-                }
-            }
-            cur[i] = best;
-            acc[(size_t)i * N + j] = best;
-            back[(size_t)i * N + j] = (int8_t)s;
-        }
-        // the diagonals are the only cross-thread traffic: LDS-only barrier when they live in LDS, so that the acc /
-        // back-pointer stores of this diagonal stay in flight
-        if constexpr (WS)
-            __syncthreads();
-        else
-            lds_barrier();
-    };
-    fetch(ca, 0);
-    fetch(cb, 1);
-    for (int d = 0; d < n_diag; d += 3) {
-        fetch(cc, d + 2);
-        step(ca, d);
-        if (d + 1 < n_diag) {
-            fetch(ca, d + 3);
-            step(cb, d + 1);
-        }
-        if (d + 2 < n_diag) {
-            fetch(cb, d + 4);
-            step(cc, d + 2);
-        }
-    }
-    __syncthreads();  // back-pointers visible to the lane that walks them
-
-    // ---- backtrack (dtw.py:43-52).  One lane walks the back-pointers, but not through HBM one dependent load at a
-    // time: the workgroup stages the 64 x 64 tile whose bottom-right corner is the walk's position in LDS, the lane
-    // walks until it leaves the tile (at least 64 steps), and so on.
-    constexpr int kT = 64;
-    __shared__ int s_len, s_i, s_j;
-    __shared__ int8_t s_tile[kT][kT + 4];
     int32_t *path = g.path + (size_t)pair * (M + N) * 2;
-    if (tid == 0) {
-        path[0] = M - 1;
-        path[1] = N - 1;
-        s_len = 1;
-        s_i = M - 1;
-        s_j = N - 1;
-    }
+    const uint32_t *codes = g.codes + (size_t)pair * sdp::codes_words(M, N);
+    const int len = sdp::backtrack(codes, M, N, path, M + N, win);
     __syncthreads();
-    while (s_i > 0 || s_j > 0) {  // uniform: shared values only change behind barriers
-        const int i0 = s_i, j0 = s_j;
-        const int ti = (i0 - kT + 1 > 0) ? i0 - kT + 1 : 0, tj = (j0 - kT + 1 > 0) ? j0 - kT + 1 : 0;
-        const int th = i0 - ti + 1, tw = j0 - tj + 1;
-        for (int idx = tid; idx < th * tw; idx += NT) {
-            const int r = idx / tw, q = idx - r * tw;
-            s_tile[r][q] = back[(size_t)(ti + r) * N + (tj + q)];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int i = i0, j = j0, len = s_len;
-            while (i >= ti && j >= tj && (i > 0 || j > 0)) {
-                const int s = s_tile[i - ti][j - tj];
-                if (s == 0)
-                    j -= 1;
-                else if (s == 1)
-                    i -= 1;
-                else {
-                    i -= 1;
-                    j -= 1;
-                }
-                path[2 * len] = i;
-                path[2 * len + 1] = j;
-                len++;
-            }
-            s_len = len;
-            s_i = i;
-            s_j = j;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) g.path_len[pair] = s_len;
-    __syncthreads();
-    const int len = s_len;
-    for (int p = tid; p < len / 2; p += NT) {  // path.reverse()
+    for (int p = lane; p < len / 2; p += 64) {  // path.reverse()
         const int q = len - 1 - p;
         const int x0 = path[2 * p], y0 = path[2 * p + 1];
         const int x1 = path[2 * q], y1 = path[2 * q + 1];
@@ -212,46 +92,68 @@ __global__ void __launch_bounds__(NT) dtw_dp_kernel(DtwArgs g) {
         path[2 * q] = x0;
         path[2 * q + 1] = y0;
     }
+    if (lane == 0) g.path_len[pair] = (*g.err != 0) ? -1 : len;
+}
+
+__global__ void __launch_bounds__(256) dtw_back_decode_kernel(DtwArgs g) {
+    const int pair = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= g.N) return;
+    const uint32_t *codes = g.codes + (size_t)pair * sdp::codes_words(g.M, g.N);
+    const int l = i & 63, t = j + l;
+    const uint32_t w = codes[((size_t)(i >> 6) * sdp::n_chunks(g.N) + (t >> 4)) * 64 + l];
+    g.back[((size_t)pair * g.M + i) * g.N + j] = (int8_t)((w >> (2 * (t & 15))) & 3);
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int dtw_waves() {  // tuning knob (results do not depend on it): waves per workgroup for multi-row-group pairs
+    const char *e = getenv("RTS_SDP_WAVES");
+    int v = e ? atoi(e) : 4;
+    if (v < 1) v = 1;
+    if (v > sdp::kMaxWaves) v = sdp::kMaxWaves;
+    return v;
 }
 
 }  // namespace rts
 
 extern "C" {
 
-int rts_dtw_workspace_bytes(int M, int N, int B, size_t *back_bytes) {
+int rts_dtw_workspace_bytes(int M, int N, int B, size_t *bytes) {
     using namespace rts;
-    if (!back_bytes) return set_error(RTS_ERR_INVALID, "back_bytes is NULL");
+    if (!bytes) return set_error(RTS_ERR_INVALID, "bytes is NULL");
     if (M < 1 || N < 1 || B < 1) return set_error(RTS_ERR_INVALID, "M, N, B must be >= 1");
-    *back_bytes = (size_t)B * M * N;
+    *bytes = 256 + align256(sizeof(unsigned long long) * (size_t)B * sdp::n_strips(M) * N) +
+             align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N));
     return RTS_OK;
 }
 
 int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_dev, int b_dtype,
             long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
-            int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, void *stream) {
-    return rts_dtw_ws(a_dev, a_dtype, a_stride, b_dev, b_dtype, b_stride, F, M, N, B, cost_dev, acc_dev, back_dev,
-                      path_dev, path_len_dev, nullptr, stream);
-}
-
-int rts_dtw_ws(const void *a_dev, int a_dtype, long long a_stride, const void *b_dev, int b_dtype,
-               long long b_stride, int F, int M, int N, int B, double *cost_dev, double *acc_dev,
-               int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, double *diag_ws_dev, void *stream) {
+            int8_t *back_dev, int32_t *path_dev, int32_t *path_len_dev, void *ws_dev, size_t ws_bytes,
+            void *stream) {
     using namespace rts;
-    if (!a_dev || !b_dev || !cost_dev || !acc_dev || !back_dev || !path_dev || !path_len_dev)
+    if (!a_dev || !b_dev || !cost_dev || !acc_dev || !path_dev || !path_len_dev || !ws_dev)
         return set_error(RTS_ERR_INVALID, "NULL device buffer");
     if (F != kDtwF) return set_error(RTS_ERR_UNSUPPORTED, "F must be 12 chroma bins (got %d)", F);
     if (M < 1 || N < 1 || B < 1) return set_error(RTS_ERR_INVALID, "M, N, B must be >= 1 (got %d %d %d)", M, N, B);
     if ((a_dtype != RTS_F32 && a_dtype != RTS_F64) || (b_dtype != RTS_F32 && b_dtype != RTS_F64))
         return set_error(RTS_ERR_INVALID, "bad dtype");
-    size_t smem = sizeof(double) * 3 * (size_t)M;
-    const bool in_lds = smem <= 150 * 1024;
-    if (!in_lds && !diag_ws_dev)
-        return set_error(RTS_ERR_UNSUPPORTED,
-                         "M=%d rows exceed the %d the LDS-resident DP sweep holds; call rts_dtw_ws with a "
-                         "B*3*M-double workspace", M, (int)(150 * 1024 / 24));
-    if (!in_lds) smem = 64;
     if ((long long)M * N > 0x7fffffffLL * 4) return set_error(RTS_ERR_INVALID, "M*N too large");
+    if (B > 65535) return set_error(RTS_ERR_INVALID, "at most 65535 pairs per call");
+    size_t need = 0;
+    rts_dtw_workspace_bytes(M, N, B, &need);
+    if (ws_bytes < need)
+        return set_error(RTS_ERR_INVALID, "workspace of %zu bytes is smaller than rts_dtw_workspace_bytes = %zu", ws_bytes, need);
+    if (((uintptr_t)ws_dev & 15) != 0) return set_error(RTS_ERR_INVALID, "workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    const int strips = sdp::n_strips(M);
+    const int NW = strips <= sdp::kMaxWaves ? strips : dtw_waves();
+    const int n_rg = (strips + NW - 1) / NW;
+    int G = 256 / B;  // every workgroup of a multi-row-group pipeline must be resident: at most one per CU
+    if (G < 1) G = 1;
+    if (G > n_rg) G = n_rg;
+    unsigned char *ws = reinterpret_cast<unsigned char *>(ws_dev);
     DtwArgs g;
     g.a = a_dev;
     g.b = b_dev;
@@ -266,38 +168,25 @@ int rts_dtw_ws(const void *a_dev, int a_dtype, long long a_stride, const void *b
     g.N = N;
     g.a_f64 = a_dtype == RTS_F64;
     g.b_f64 = b_dtype == RTS_F64;
-    g.diag_ws = in_lds ? nullptr : diag_ws_dev;
+    g.err = reinterpret_cast<int32_t *>(ws);
+    g.bnd = reinterpret_cast<unsigned long long *>(ws + 256);
+    g.codes = reinterpret_cast<uint32_t *>(ws + 256 + align256(sizeof(unsigned long long) * (size_t)B * strips * N));
+    g.n_rg = n_rg;
+    RTS_HIP(hipMemsetAsync(g.err, 0, 16, s));
+    if (n_rg > 1) RTS_HIP(hipMemsetD32Async((hipDeviceptr_t)g.bnd, (int)sdp::kSentinel32, (size_t)2 * B * strips * N, s));
     hipLaunchKernelGGL(dtw_cost_kernel, dim3((N + 63) / 64, (M + 3) / 4, B), dim3(256), 0, s, g);
     RTS_HIP(hipGetLastError());
-    // one row per thread up to 1024 rows; fewer waves for small M keeps the per-diagonal barrier cheap
-    if (!in_lds) {
-        hipLaunchKernelGGL((dtw_dp_kernel<1024, true>), dim3(B), dim3(1024), smem, s, g);
-    } else if (M <= 256) {
-        static bool done = false;
-        if (!done) {
-            RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_dp_kernel<256, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            done = true;
-        }
-        hipLaunchKernelGGL((dtw_dp_kernel<256, false>), dim3(B), dim3(256), smem, s, g);
-    } else if (M <= 512) {
-        static bool done = false;
-        if (!done) {
-            RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_dp_kernel<512, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            done = true;
-        }
-        hipLaunchKernelGGL((dtw_dp_kernel<512, false>), dim3(B), dim3(512), smem, s, g);
-    } else {
-        static bool done = false;
-        if (!done) {
-            RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_dp_kernel<1024, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            done = true;
-        }
-        hipLaunchKernelGGL((dtw_dp_kernel<1024, false>), dim3(B), dim3(1024), smem, s, g);
-    }
+    const size_t smem = sdp::lds_bytes(NW, true);
+    RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(dtw_sdp_kernel, dim3(G, B), dim3(64 * NW), smem, s, g);
     RTS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(dtw_backtrack_kernel, dim3(B), dim3(64), 0, s, g);
+    RTS_HIP(hipGetLastError());
+    if (back_dev) {
+        hipLaunchKernelGGL(dtw_back_decode_kernel, dim3((N + 255) / 256, M, B), dim3(256), 0, s, g);
+        RTS_HIP(hipGetLastError());
+    }
     return RTS_OK;
 }
 

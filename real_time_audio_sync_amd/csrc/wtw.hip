@@ -11,11 +11,14 @@
 //      cells of a diagonal are independent, so D and B are bit-identical to the serial loops,
 //   3. backtracks B and applies the hand-over rule of wtw.py:107-128 (append sub-path points with
 //      l <= dtw_hop/hop, move (live_ptr, ref_ptr) to the last appended point) on one lane.
-// The back-pointer matrix lives in LDS for W <= 128 and in an HBM workspace above that.  Windows of
-// more than 512 frames (BASELINE configs[4]: W = 10 000) do not fit LDS at all: the same code then
-// runs with 1024 threads, reads the window's features in place from HBM/L2 and keeps norms, the
-// three diagonals and the sub-path in a per-stream HBM workspace (workgroup-scope visibility through
-// the barrier is all the single-workgroup sweep needs).
+// The back-pointer matrix lives in LDS for W <= 128 and in an HBM workspace above that.
+//
+// Windows of more than 512 frames (BASELINE configs[4]: W = 10 000) are a different regime -- one window is
+// 1e8 cells -- and run as a strip DP (sdp.h) spread over many workgroups: per window one launch of
+// wtw_big_dp_kernel (a pipeline of row groups down the W x W matrix, step codes packed 2 bits per cell) and one
+// of wtw_big_ctl_kernel (backtrack over the packed codes, hand-over, then the column bookkeeping of
+// wtw.py:92-100 up to the next window).  The host enqueues as many (dp, ctl) rounds as the pushed columns can
+// possibly complete windows; rounds with nothing pending return at once.  Everything stays asynchronous.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -23,6 +26,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "sdp.h"
 
 namespace rts {
 
@@ -40,8 +44,13 @@ struct WtwArgs {
     int32_t *path;        // [B][path_cap][2]
     int8_t *bwork;        // [B][W][W] or NULL when W <= kWtwLdsB
     double *dlast;        // [B][W][W] last window's D (optional, NULL = not stored)
-    double *ws;           // W > kWtwLdsW: [B][5W] doubles (nx, ny, 3 diagonals) ...
-    int32_t *ws_sub;      // ... and [B][4W] ints (sub-path)
+    // W > kWtwLdsW (strip DP):
+    int32_t *ws_sub;           // [B][4W] ints: the window's sub-path, reversed
+    int32_t *ctl;              // [B][8]: pending, live_ptr, ref_ptr, n, m of the window being computed
+    uint32_t *codes;           // [B][codes_words(W, W)] packed step codes
+    unsigned long long *bnd;   // [B][n_strips(W)][W] rows handed between row groups
+    int32_t *err;
+    int n_rg;
     int M, N, W, hopf, path_cap;
 };
 
@@ -66,21 +75,19 @@ __device__ __forceinline__ double wtw_dot_strided(const double *x, const double 
     return t1 + t2;
 }
 
-// BIG: window state in the HBM workspace (W > kWtwLdsW), 1024 threads; else LDS, 256 threads.  BL: back-pointers in
-// LDS (W <= kWtwLdsB) rather than HBM.  Compile-time, so that every pointer has a known address space.
-template <bool BIG, bool BL>
-__global__ void __launch_bounds__(BIG ? 1024 : 256) wtw_advance_kernel(WtwArgs g) {
+// Windows of up to kWtwLdsW frames: window state in LDS, 256 threads.  BL: back-pointers in LDS (W <= kWtwLdsB)
+// rather than HBM.  Compile-time, so that every pointer has a known address space.
+template <bool BL>
+__global__ void __launch_bounds__(256) wtw_advance_kernel(WtwArgs g) {
     extern __shared__ __align__(16) unsigned char wtw_smem[];
     const int W = g.W;
     const int b = blockIdx.x, tid = threadIdx.x;
-    constexpr int kWtwNT = BIG ? 1024 : 256;  // = blockDim.x
-    constexpr bool big = BIG;
-    double *xs_l = reinterpret_cast<double *>(wtw_smem);  // [W][F] live window   (LDS-resident case)
-    double *ys_l = xs_l + (size_t)(big ? 0 : W) * kWF;    // [W][F] ref window
-    double *nx = big ? g.ws + (size_t)b * 5 * W : ys_l + (size_t)W * kWF;  // [W]
-    double *ny = nx + W;                                                   // [W]
-    double *diag = ny + W;                                                 // [3][W]
-    int32_t *sub = big ? g.ws_sub + (size_t)b * 4 * W : reinterpret_cast<int32_t *>(diag + 3 * (size_t)W);  // [2W][2]
+    double *xs_l = reinterpret_cast<double *>(wtw_smem);  // [W][F] live window
+    double *ys_l = xs_l + (size_t)W * kWF;                // [W][F] ref window
+    double *nx = ys_l + (size_t)W * kWF;                  // [W]
+    double *ny = nx + W;                                  // [W]
+    double *diag = ny + W;                                // [3][W]
+    int32_t *sub = reinterpret_cast<int32_t *>(diag + 3 * (size_t)W);  // [2W][2]
     int8_t *bl = reinterpret_cast<int8_t *>(sub + 4 * (size_t)W);  // [W][W] when W <= kWtwLdsB
     __shared__ int s_chroma_ptr, s_live_ptr, s_ref_ptr, s_status, s_n_path, s_n_windows, s_go;
     __shared__ long long s_cells;
@@ -131,13 +138,9 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) wtw_advance_kernel(WtwArgs g
             int m = W;
             if (rp + m > g.M) m = g.M - rp;  // numpy slice truncation of chroma_ref[:, rp:rp+W]
             if (m <= 0) break;
-            const double *xs = live + (size_t)lp * kWF, *ys = g.ref + (size_t)rp * kWF;  // in place when big
-            if (!big) {
-                for (int idx = tid; idx < n * kWF; idx += kWtwNT) xs_l[idx] = live[(size_t)lp * kWF + idx];
-                for (int idx = tid; idx < m * kWF; idx += kWtwNT) ys_l[idx] = g.ref[(size_t)rp * kWF + idx];
-                xs = xs_l;
-                ys = ys_l;
-            }
+            for (int idx = tid; idx < n * kWF; idx += kWtwNT) xs_l[idx] = live[(size_t)lp * kWF + idx];
+            for (int idx = tid; idx < m * kWF; idx += kWtwNT) ys_l[idx] = g.ref[(size_t)rp * kWF + idx];
+            const double *xs = xs_l, *ys = ys_l;
             __syncthreads();
             for (int i = tid; i < n; i += kWtwNT) nx[i] = sqrt(wtw_dot_chain(xs + i * kWF, xs + i * kWF));
             for (int j = tid; j < m; j += kWtwNT) ny[j] = sqrt(wtw_dot_chain(ys + j * kWF, ys + j * kWF));
@@ -182,10 +185,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) wtw_advance_kernel(WtwArgs g
                     Bm[(size_t)i * W + j] = code;
                     if (g.dlast) g.dlast[((size_t)b * W + i) * W + j] = dv;
                 }
-                if (big)
-                    __syncthreads();
-                else
-                    lds_barrier();  // diagonals in LDS: leave the back-pointer / D stores in flight
+                lds_barrier();  // diagonals in LDS: leave the back-pointer / D stores in flight
             }
             __syncthreads();  // back-pointers (HBM for W > 128) visible to the lane that walks them
             if (tid == 0) {
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) wtw_advance_kernel(WtwArgs g
                 sub[0] = i;
                 sub[1] = j;
                 len = 1;
-                while (!(i == 0 && j == 0) && len < 2 * W) {  // B in HBM for W > 128: ~1 us per step
+                while (!(i == 0 && j == 0) && len < 2 * W) {
                     const int8_t p = Bm[(size_t)i * W + j];
                     if (p == 1)
                         j -= 1;
@@ -252,6 +252,130 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) wtw_advance_kernel(WtwArgs g
     }
 }
 
+// ---- windows of more than kWtwLdsW frames: strip DP over many workgroups (sdp.h) ------------------------------
+
+template <bool STAGE>
+__global__ void __launch_bounds__(512) wtw_big_dp_kernel(WtwArgs g) {
+    extern __shared__ __align__(16) unsigned char wtw_smem[];
+    const int b = blockIdx.y;
+    const int32_t *ctl = g.ctl + (size_t)b * 8;
+    if (ctl[0] == 0) return;  // no window pending for this stream
+    const int lp = ctl[1], rp = ctl[2];
+    sdp::Problem pb;
+    pb.x = g.live + ((size_t)b * g.N + lp) * kWF;  // rows: the live window (wtw.py:101)
+    pb.y = g.ref + (size_t)rp * kWF;               // columns: the reference window (wtw.py:102)
+    pb.x_f64 = 1;
+    pb.y_f64 = 1;
+    pb.M = ctl[3];
+    pb.N = ctl[4];
+    pb.D = STAGE ? g.dlast + (size_t)b * g.W * g.W : nullptr;
+    pb.ldD = g.W;
+    pb.codes = g.codes + (size_t)b * sdp::codes_words(g.W, g.W);
+    pb.bnd = g.bnd + (size_t)b * sdp::n_strips(g.W) * g.W;
+    pb.err = g.err;
+    const int NW = blockDim.x >> 6;
+    for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x) sdp::run_rowgroup<sdp::WtwPolicy, STAGE>(pb, rg, g.n_rg, NW, wtw_smem);
+}
+
+// One workgroup per stream.  If a window is pending (its step codes were just written by wtw_big_dp_kernel):
+// find_path (wtw.py:219-240) + hand-over (wtw.py:107-128).  Then the column bookkeeping of wtw.py:92-100 in closed
+// form up to the next event: between two windows the stop test (wtw.py:96) sees constant pointers, and a window
+// fires exactly when chroma_ptr reaches live_ptr + W.
+__global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) {
+    __shared__ uint32_t win[sdp::kBtChunks * 64];
+    __shared__ int s_len, s_cnt;
+    const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    const int W = g.W;
+    int32_t *st = g.state + (size_t)b * 8;
+    int32_t *ctl = g.ctl + (size_t)b * 8;
+    int32_t *sub = g.ws_sub + (size_t)b * 4 * W;
+    int32_t *path = g.path + (size_t)b * g.path_cap * 2;
+    const int pending = ctl[0];
+    int lp = ctl[1], rp = ctl[2];
+    const int n = ctl[3], m = ctl[4];
+    int live_ptr = st[1], ref_ptr = st[2], n_path = st[4];
+    if (tid == 0) s_cnt = 0;
+    if (pending) {
+        if (tid < 64) {
+            const int len = sdp::backtrack(g.codes + (size_t)b * sdp::codes_words(W, W), n, m, sub, 2 * W, win);
+            if (tid == 0) s_len = len;
+        }
+        __syncthreads();
+        // sub[] holds the path reversed; l is non-decreasing along the forward path, so the points handed over
+        // (l <= dtw_hop / hop, wtw.py:113) are a prefix of it
+        const int len = s_len;
+        int local = 0;
+        for (int q = tid; q < len; q += NT) local += (sub[2 * q] <= g.hopf) ? 1 : 0;
+        if (local) atomicAdd(&s_cnt, local);
+        __syncthreads();
+        const int cnt = s_cnt;
+        for (int f = tid; f < cnt; f += NT) {
+            const int q = len - 1 - f;
+            if (n_path + f < g.path_cap) {
+                path[2 * (size_t)(n_path + f)] = sub[2 * q] + lp;
+                path[2 * (size_t)(n_path + f) + 1] = sub[2 * q + 1] + rp;
+            }
+        }
+        if (cnt < len) {  // "change": the path went past the hop (wtw.py:118-124)
+            const int q = len - cnt;  // last appended point = forward index cnt - 1
+            live_ptr = lp + sub[2 * q];
+            ref_ptr = rp + sub[2 * q + 1];
+        } else {
+            live_ptr = lp + g.hopf;
+            ref_ptr = rp + g.hopf;
+        }
+        n_path += cnt;
+    }
+    __syncthreads();
+    // ---- bookkeeping up to the next event (uniform across the workgroup: everything below depends on state only)
+    const int appended_raw = g.appended[b];
+    const int appended = appended_raw < g.N ? appended_raw : g.N;
+    int chroma_ptr = st[0], status = st[3], n_windows = st[5];
+    long long cells = ((long long)(uint32_t)st[7] << 32) | (uint32_t)st[6];
+    if (pending) {
+        n_windows += 1;
+        cells += (long long)n * m;
+    }
+    int next_pending = 0, nn = 0, nm = 0;
+    if (status == RTS_RUNNING && chroma_ptr < appended) {
+        if (ref_ptr >= (g.M - 1 - W) || live_ptr >= (g.N - 1 - W)) {
+            chroma_ptr += 1;  // wtw.py:92-97: the next column trips the boundary check
+            status = RTS_STOP_REF_END;
+        } else if (live_ptr + W <= appended) {
+            chroma_ptr = live_ptr + W;  // the column that completes the window (wtw.py:100)
+            nn = W;
+            nm = W;
+            if (ref_ptr + nm > g.M) nm = g.M - ref_ptr;  // numpy slice truncation of chroma_ref[:, rp:rp+W]
+            next_pending = nm > 0 ? 1 : 0;
+            if (!next_pending) chroma_ptr = appended;  // unreachable (wtw.py:96 stops first); never stall
+        } else {
+            chroma_ptr = appended;
+        }
+    }
+    if (!next_pending && status == RTS_RUNNING && chroma_ptr >= g.N && appended_raw > g.N) status = RTS_LIVE_OVERFLOW;
+    if (next_pending) {  // hand the window to the DP launch that follows; its boundary words start as "not written"
+        unsigned long long *bnd = g.bnd + (size_t)b * sdp::n_strips(W) * W;
+        const size_t words = (size_t)(g.n_rg > 1 ? g.n_rg - 1 : 0) * nm;
+        for (size_t k = tid; k < words; k += NT) bnd[k] = sdp::kSentinel;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        st[0] = chroma_ptr;
+        st[1] = live_ptr;
+        st[2] = ref_ptr;
+        st[3] = (*g.err != 0 && status == RTS_RUNNING) ? RTS_DEVICE_FAULT : status;
+        st[4] = n_path;
+        st[5] = n_windows;
+        st[6] = (int32_t)(uint32_t)(cells & 0xffffffffLL);
+        st[7] = (int32_t)(uint32_t)((unsigned long long)cells >> 32);
+        ctl[0] = next_pending;
+        ctl[1] = live_ptr;
+        ctl[2] = ref_ptr;
+        ctl[3] = nn;
+        ctl[4] = nm;
+    }
+}
+
 // wtw.py:76-77: the check made at the top of insert(), before any column is processed.
 __global__ void wtw_precheck_kernel(int32_t *state, int B, int M, int N) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,8 +418,10 @@ struct rts_wtw {
     int32_t *appended, *state, *path;
     int8_t *bwork;
     double *dlast;
-    double *ws;
-    int32_t *ws_sub;
+    int32_t *ws_sub, *ctl, *err;
+    uint32_t *codes;
+    unsigned long long *bnd;
+    int big_waves, n_rg, big_grid;
     size_t smem;
 };
 
@@ -325,22 +451,42 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     h->path_cap = (h->N / hop_frames + 2) * (win_frames + hop_frames + 2);
     const int W = win_frames;
     const bool big = W > kWtwLdsW;
-    h->smem = big ? 64
-                  : sizeof(double) * ((size_t)2 * W * kWF + 2 * W + 3 * W) + sizeof(int32_t) * 4 * W +
-                        (W <= kWtwLdsB ? (size_t)W * W : 0) + 64;
+    if (big) {
+        const char *env = getenv("RTS_SDP_WAVES");  // tuning knob; results do not depend on it
+        int nw = env ? atoi(env) : 4;
+        if (nw < 1) nw = 1;
+        if (nw > sdp::kMaxWaves) nw = sdp::kMaxWaves;
+        h->big_waves = nw;
+        h->n_rg = (sdp::n_strips(W) + nw - 1) / nw;
+        int grid = 256 / B;  // every workgroup of a stream's pipeline must be resident: at most one per CU
+        if (grid < 1) grid = 1;
+        if (grid > h->n_rg) grid = h->n_rg;
+        h->big_grid = grid;
+        h->smem = sdp::lds_bytes(nw, keep_last_d != 0);
+    } else {
+        h->smem = sizeof(double) * ((size_t)2 * W * kWF + 2 * W + 3 * W) + sizeof(int32_t) * 4 * W +
+                  (W <= kWtwLdsB ? (size_t)W * W : 0) + 64;
+    }
     hipError_t e;
     if ((e = hipMalloc((void **)&h->live, sizeof(double) * kWF * (size_t)h->N * B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->appended, sizeof(int32_t) * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->state, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->path, sizeof(int32_t) * 2 * (size_t)h->path_cap * B)) != hipSuccess ||
-        (W > kWtwLdsB && (e = hipMalloc((void **)&h->bwork, (size_t)B * W * W)) != hipSuccess) ||
-        (big && (e = hipMalloc((void **)&h->ws, sizeof(double) * 5 * (size_t)W * B)) != hipSuccess) ||
+        (!big && W > kWtwLdsB && (e = hipMalloc((void **)&h->bwork, (size_t)B * W * W)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->ws_sub, sizeof(int32_t) * 4 * (size_t)W * B)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->ctl, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->err, 16)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->codes, sizeof(uint32_t) * sdp::codes_words(W, W) * B)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->bnd, sizeof(unsigned long long) * (size_t)sdp::n_strips(W) * W * B)) != hipSuccess) ||
         (keep_last_d && (e = hipMalloc((void **)&h->dlast, sizeof(double) * (size_t)B * W * W)) != hipSuccess) ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<false, true>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<false, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) {
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) {
         rts_wtw_destroy(h);
         return set_error(RTS_ERR_HIP, "WTW allocation failed: %s", hipGetErrorString(e));
     }
@@ -349,7 +495,10 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         rts_wtw_destroy(h);
         return rc;
     }
-    RTS_HIP(hipStreamSynchronize(nullptr));
+    if (hipError_t es = hipStreamSynchronize(nullptr); es != hipSuccess) {
+        rts_wtw_destroy(h);
+        return set_error(RTS_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
+    }
     *out = h;
     return RTS_OK;
 }
@@ -362,8 +511,11 @@ int rts_wtw_destroy(rts_wtw *h) {
     if (h->path) (void)hipFree(h->path);
     if (h->bwork) (void)hipFree(h->bwork);
     if (h->dlast) (void)hipFree(h->dlast);
-    if (h->ws) (void)hipFree(h->ws);
     if (h->ws_sub) (void)hipFree(h->ws_sub);
+    if (h->ctl) (void)hipFree(h->ctl);
+    if (h->err) (void)hipFree(h->err);
+    if (h->codes) (void)hipFree(h->codes);
+    if (h->bnd) (void)hipFree(h->bnd);
     free(h);
     return RTS_OK;
 }
@@ -376,6 +528,8 @@ int rts_wtw_reset(rts_wtw *h, void *stream) {
     RTS_HIP(hipMemsetAsync(h->state, 0, sizeof(int32_t) * 8 * (size_t)h->B, s));
     // wtw.py:55: chroma_live starts as zeros
     RTS_HIP(hipMemsetAsync(h->live, 0, sizeof(double) * kWF * (size_t)h->N * h->B, s));
+    if (h->ctl) RTS_HIP(hipMemsetAsync(h->ctl, 0, sizeof(int32_t) * 8 * (size_t)h->B, s));
+    if (h->err) RTS_HIP(hipMemsetAsync(h->err, 0, 16, s));
     return RTS_OK;
 }
 
@@ -403,19 +557,34 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.path = h->path;
     g.bwork = h->bwork;
     g.dlast = h->dlast;
-    g.ws = h->ws;
     g.ws_sub = h->ws_sub;
+    g.ctl = h->ctl;
+    g.codes = h->codes;
+    g.bnd = h->bnd;
+    g.err = h->err;
+    g.n_rg = h->n_rg;
     g.M = h->M;
     g.N = h->N;
     g.W = h->W;
     g.hopf = h->hopf;
     g.path_cap = h->path_cap;
-    if (h->W > kWtwLdsW)
-        hipLaunchKernelGGL((wtw_advance_kernel<true, false>), dim3(h->B), dim3(1024), h->smem, s, g);
-    else if (h->W > kWtwLdsB)
-        hipLaunchKernelGGL((wtw_advance_kernel<false, false>), dim3(h->B), dim3(kWtwNT), h->smem, s, g);
-    else
-        hipLaunchKernelGGL((wtw_advance_kernel<false, true>), dim3(h->B), dim3(kWtwNT), h->smem, s, g);
+    if (h->W > kWtwLdsW) {
+        // one (dp, ctl) round per window the new columns can complete: the first needs at least one column, every
+        // further one dtw_hop / hop more (the live pointer advances by exactly that per window, wtw.py:118-128)
+        const int rounds = n_max / h->hopf + 1;
+        hipLaunchKernelGGL(wtw_big_ctl_kernel, dim3(h->B), dim3(1024), 0, s, g);
+        for (int r = 0; r < rounds; r++) {
+            if (h->dlast)
+                hipLaunchKernelGGL((wtw_big_dp_kernel<true>), dim3(h->big_grid, h->B), dim3(64 * h->big_waves), h->smem, s, g);
+            else
+                hipLaunchKernelGGL((wtw_big_dp_kernel<false>), dim3(h->big_grid, h->B), dim3(64 * h->big_waves), h->smem, s, g);
+            hipLaunchKernelGGL(wtw_big_ctl_kernel, dim3(h->B), dim3(1024), 0, s, g);
+        }
+    } else if (h->W > kWtwLdsB) {
+        hipLaunchKernelGGL((wtw_advance_kernel<false>), dim3(h->B), dim3(kWtwNT), h->smem, s, g);
+    } else {
+        hipLaunchKernelGGL((wtw_advance_kernel<true>), dim3(h->B), dim3(kWtwNT), h->smem, s, g);
+    }
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

@@ -9,10 +9,11 @@ from . import _native as nat
 from .otw_batch import frames_tensor, _np_dtype_code
 
 
-def dtw_batch(a_dev, b_dev, stream_device=None):
+def dtw_batch(a_dev, b_dev, want_back=True):
     """a_dev: [B][M][12] or [M][12] (shared), b_dev: [B][N][12] or [N][12] (shared); device
     tensors, float32/float64.  Returns device tensors (cost [B][M][N] f64, acc [B][M][N] f64,
-    back [B][M][N] int8, path [B][M+N][2] int32, path_len [B] int32).  Asynchronous."""
+    back [B][M][N] int8 -- None unless want_back --, path [B][M+N][2] int32, path_len [B] int32).
+    Asynchronous."""
     dev = a_dev.device
     sa = a_dev.dim() == 2
     sb = b_dev.dim() == 2
@@ -21,16 +22,18 @@ def dtw_batch(a_dev, b_dev, stream_device=None):
     a_dev, b_dev = a_dev.contiguous(), b_dev.contiguous()
     cost = torch.empty((B, M, N), dtype=torch.float64, device=dev)
     acc = torch.empty((B, M, N), dtype=torch.float64, device=dev)
-    back = torch.empty((B, M, N), dtype=torch.int8, device=dev)
+    back = torch.empty((B, M, N), dtype=torch.int8, device=dev) if want_back else None
     path = torch.empty((B, M + N, 2), dtype=torch.int32, device=dev)
     plen = torch.zeros((B,), dtype=torch.int32, device=dev)
-    # sequences of more than 6400 frames keep their three anti-diagonals in an HBM workspace
-    ws = torch.empty((B, 3, M), dtype=torch.float64, device=dev) if M > 6400 else None
-    nat.check(nat.lib.rts_dtw_ws(a_dev.data_ptr(), _np_dtype_code(a_dev.dtype), 0 if sa else M,
-                                 b_dev.data_ptr(), _np_dtype_code(b_dev.dtype), 0 if sb else N,
-                                 12, M, N, B, cost.data_ptr(), acc.data_ptr(), back.data_ptr(), path.data_ptr(),
-                                 plen.data_ptr(), ws.data_ptr() if ws is not None else None,
-                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    nbytes = ctypes.c_size_t(0)
+    nat.check(nat.lib.rts_dtw_workspace_bytes(M, N, B, ctypes.byref(nbytes)))
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+    nat.check(nat.lib.rts_dtw(a_dev.data_ptr(), _np_dtype_code(a_dev.dtype), 0 if sa else M,
+                              b_dev.data_ptr(), _np_dtype_code(b_dev.dtype), 0 if sb else N,
+                              12, M, N, B, cost.data_ptr(), acc.data_ptr(),
+                              back.data_ptr() if back is not None else None, path.data_ptr(),
+                              plen.data_ptr(), ws.data_ptr(), nbytes.value,
+                              ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return cost, acc, back, path, plen
 
 
@@ -42,6 +45,8 @@ def DTW(seq_a, seq_b, device="cuda:0"):
     dev = torch.device(device)
     a = frames_tensor(np.asarray(seq_a, dtype=np.float64), dev)
     b = frames_tensor(np.asarray(seq_b, dtype=np.float64), dev)
-    cost, acc, _, path, plen = dtw_batch(a, b)
+    cost, acc, _, path, plen = dtw_batch(a, b, want_back=False)
     n = int(plen[0].item())
+    if n < 1:
+        raise nat.RtsyncError("rts_dtw: the device pipeline reported a fault")
     return cost[0].cpu().numpy(), acc[0].cpu().numpy(), path[0, :n].cpu().numpy().astype(np.int64)
