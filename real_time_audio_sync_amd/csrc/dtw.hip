@@ -37,21 +37,28 @@ struct DtwArgs {
     int n_rg;
 };
 
-__device__ __forceinline__ double dtw_load(const void *p, int f64, long long idx) {
-    return f64 ? reinterpret_cast<const double *>(p)[idx] : (double)reinterpret_cast<const float *>(p)[idx];
-}
+// One thread per column j and kCostRows consecutive rows: b_j stays in registers, the a rows are wave-uniform
+// (broadcast) loads, every store instruction writes 512 contiguous bytes of one row.
+constexpr int kCostRows = 32;
 
+template <bool A64, bool B64>
 __global__ void __launch_bounds__(256) dtw_cost_kernel(DtwArgs g) {
     const int pair = blockIdx.z;
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= g.M || j >= g.N) return;
-    const long long ao = ((long long)pair * g.a_stride + i) * kDtwF;
-    const long long bo = ((long long)pair * g.b_stride + j) * kDtwF;
-    double s = 0.0;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * kCostRows;
+    if (j >= g.N) return;
+    double b[kDtwF];
+    sdp::load_frame(g.b, B64, (long long)pair * g.b_stride + j, b);
+    double *out = g.cost + ((size_t)pair * g.M + i0) * g.N + j;
+    const int rows = (g.M - i0 < kCostRows) ? g.M - i0 : kCostRows;
+    for (int r = 0; r < rows; r++) {
+        double a[kDtwF];
+        sdp::load_frame(g.a, A64, (long long)pair * g.a_stride + i0 + r, a);
+        double s = 0.0;
 #pragma unroll
-    for (int f = 0; f < kDtwF; f++) s = fma(dtw_load(g.a, g.a_f64, ao + f), dtw_load(g.b, g.b_f64, bo + f), s);
-    g.cost[((size_t)pair * g.M + i) * g.N + j] = 1.0 - s;
+        for (int f = 0; f < kDtwF; f++) s = fma(a[f], b[f], s);
+        out[(size_t)r * g.N] = 1.0 - s;
+    }
 }
 
 __global__ void __launch_bounds__(512) dtw_sdp_kernel(DtwArgs g) {
@@ -76,7 +83,7 @@ __global__ void __launch_bounds__(512) dtw_sdp_kernel(DtwArgs g) {
 }
 
 __global__ void __launch_bounds__(64) dtw_backtrack_kernel(DtwArgs g) {
-    __shared__ uint32_t win[sdp::kBtChunks * 64];
+    __shared__ uint32_t win[2 * sdp::kBtChunks * 64];
     const int pair = blockIdx.x, lane = threadIdx.x;
     const int M = g.M, N = g.N;
     int32_t *path = g.path + (size_t)pair * (M + N) * 2;
@@ -174,7 +181,17 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
     g.n_rg = n_rg;
     RTS_HIP(hipMemsetAsync(g.err, 0, 16, s));
     if (n_rg > 1) RTS_HIP(hipMemsetD32Async((hipDeviceptr_t)g.bnd, (int)sdp::kSentinel32, (size_t)2 * B * strips * N, s));
-    hipLaunchKernelGGL(dtw_cost_kernel, dim3((N + 63) / 64, (M + 3) / 4, B), dim3(256), 0, s, g);
+    {
+        const dim3 grid((N + 255) / 256, (M + kCostRows - 1) / kCostRows, B);
+        if (g.a_f64 && g.b_f64)
+            hipLaunchKernelGGL((dtw_cost_kernel<true, true>), grid, dim3(256), 0, s, g);
+        else if (g.a_f64)
+            hipLaunchKernelGGL((dtw_cost_kernel<true, false>), grid, dim3(256), 0, s, g);
+        else if (g.b_f64)
+            hipLaunchKernelGGL((dtw_cost_kernel<false, true>), grid, dim3(256), 0, s, g);
+        else
+            hipLaunchKernelGGL((dtw_cost_kernel<false, false>), grid, dim3(256), 0, s, g);
+    }
     RTS_HIP(hipGetLastError());
     const size_t smem = sdp::lds_bytes(NW, true);
     RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel),

@@ -342,7 +342,7 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
                     upprev = up;
                     prev = dv;
                     codes |= (uint32_t)code << (2 * q);
-                    asm volatile("" : "+v"(codes));  // materialise now: do not keep 48 lane masks alive
+                    asm("" : "+v"(codes));  // materialise now: do not keep 48 lane masks alive
                     {
                         const int lo = __builtin_amdgcn_readlane(__double2loint(dv), 63);
                         const int hi = __builtin_amdgcn_readlane(__double2hiint(dv), 63);
@@ -401,49 +401,77 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
 
 // ---- backtrack over the packed, skewed step codes: one wave ----------------------------------------------------
 // Walks from (M-1, N-1) to (0, 0) and writes the visited points, in walk order (i.e. reversed), as (i, j)
-// pairs to `rev`; returns the number of points.  `win` is a [kBtChunks][64] dword LDS window.
-constexpr int kBtChunks = 32;
+// pairs to `rev`; returns the number of points.  The walk is a uniform (scalar) loop: the position lives in
+// SGPRs, every lane keeps the code word of ITS row for the current 16-step chunk in a register and the step code
+// is one v_readlane away, so no step waits for a memory round trip.  A window of kBtChunks chunks of the current
+// strip is staged in LDS (`win`: [2][kBtChunks][64] dwords); the window the walk will most likely enter in the
+// strip above is fetched into registers while the current strip is being walked.
+constexpr int kBtChunks = 8;
 
 __device__ __forceinline__ int backtrack(const uint32_t *codes, int M, int N, int32_t *rev, int cap, uint32_t *win) {
     const int lane = threadIdx.x & 63;
     const int nch = n_chunks(N);
-    int i = M - 1, j = N - 1, len = 0;
+    int i = M - 1, j = N - 1, len = 1;
     if (lane == 0 && cap > 0) {
         rev[0] = i;
         rev[1] = j;
     }
-    len = 1;
-    while ((i > 0 || j > 0) && len < cap) {
-        const int strip = i >> 6;
-        const int c_hi = (j + (i & 63)) >> 4;
-        const int c_lo = c_hi - kBtChunks + 1 > 0 ? c_hi - kBtChunks + 1 : 0;
-        for (int c = c_lo; c <= c_hi; c++) win[(c - c_lo) * 64 + lane] = codes[((size_t)strip * nch + c) * 64 + lane];
+    int buf = 0;
+    // staged window: strip ws, chunks [wlo, wlo + kBtChunks)
+    int ws = -1, wlo = 0;
+    // prefetched (registers) window: strip ps, chunks [plo, plo + kBtChunks)
+    int ps = -1, plo = 0;
+    uint32_t pf[kBtChunks];
+#pragma unroll
+    for (int k = 0; k < kBtChunks; k++) pf[k] = 0;
+    auto fetch = [&](int strip, int lo) {  // chunk indices below 0 or beyond nch-1 are never walked
+#pragma unroll
+        for (int k = 0; k < kBtChunks; k++) {
+            const int c = lo + k;
+            pf[k] = (strip >= 0 && c >= 0 && c < nch) ? codes[((size_t)strip * nch + c) * 64 + lane] : 0u;
+        }
+        ps = strip;
+        plo = lo;
+    };
+    auto commit = [&]() {  // registers -> the other LDS buffer
+        buf ^= 1;
+#pragma unroll
+        for (int k = 0; k < kBtChunks; k++) win[(buf * kBtChunks + k) * 64 + lane] = pf[k];
+        ws = ps;
+        wlo = plo;
+        ps = -1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    while ((i > 0 || j > 0) && len < cap) {
+        const int strip = i >> 6;
+        const int c0 = (j + (i & 63)) >> 4;
+        if (!(ps == strip && c0 >= plo && c0 < plo + kBtChunks)) fetch(strip, c0 - kBtChunks + 1);
+        commit();
+        // the walk leaves this strip through its row 0 after at most (i & 63) + 1 upward moves; with a few moves to
+        // the left it enters the strip above at t = j' + 63 within the chunks fetched here
+        fetch(strip - 1, ((j + 63) >> 4) - kBtChunks + 1);
+        int ccur = c0;
+        uint32_t cur = win[(buf * kBtChunks + (c0 - wlo)) * 64 + lane];
+        uint32_t nxt = (c0 - 1 >= wlo) ? win[(buf * kBtChunks + (c0 - 1 - wlo)) * 64 + lane] : 0u;
         while ((i > 0 || j > 0) && len < cap) {
             const int l = i & 63, t = j + l, c = t >> 4;
-            if ((i >> 6) != strip || c < c_lo) break;
-            const uint32_t w = win[(c - c_lo) * 64 + l];
+            if ((i >> 6) != strip || c < wlo) break;
+            if (c != ccur) {  // one chunk down (t shrinks by at most 2 per step)
+                cur = nxt;
+                ccur = c;
+                nxt = (c - 1 >= wlo) ? win[(buf * kBtChunks + (c - 1 - wlo)) * 64 + lane] : 0u;
+            }
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, l);
             const int code = (w >> (2 * (t & 15))) & 3;
-            if (code == kLeft)
-                j -= 1;
-            else if (code == kUp)
-                i -= 1;
-            else {
-                i -= 1;
-                j -= 1;
-            }
-            // a corrupted code cannot leave the matrix
-            if (i < 0) i = 0;
-            if (j < 0) j = 0;
-            if (lane == 0) {
-                rev[2 * len] = i;
-                rev[2 * len + 1] = j;
-            }
+            i -= (code != kLeft) ? 1 : 0;  // kUp, kDiag
+            j -= (code != kUp) ? 1 : 0;    // kLeft, kDiag
+            i = i < 0 ? 0 : i;             // a corrupted code cannot leave the matrix
+            j = j < 0 ? 0 : j;
+            if (lane == 0) *reinterpret_cast<int2 *>(rev + 2 * (size_t)len) = make_int2(i, j);
             len++;
         }
-        __builtin_amdgcn_wave_barrier();
     }
     return len;
 }

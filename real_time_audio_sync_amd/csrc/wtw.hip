@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(512) wtw_big_dp_kernel(WtwArgs g) {
 // form up to the next event: between two windows the stop test (wtw.py:96) sees constant pointers, and a window
 // fires exactly when chroma_ptr reaches live_ptr + W.
 __global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) {
-    __shared__ uint32_t win[sdp::kBtChunks * 64];
+    __shared__ uint32_t win[2 * sdp::kBtChunks * 64];
     __shared__ int s_len, s_cnt;
     const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int W = g.W;
