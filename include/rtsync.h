@@ -139,6 +139,12 @@ int rts_otw_device_views(rts_otw *h, int32_t **path_dev, int *path_cap, int32_t 
  * written to (never-evaluated cells hold the sentinel 1e10 / +inf, resp. -1).  NULL, NULL switches it
  * off.  Resets the handle (the matrices are re-initialised on every reset / run). */
 int rts_otw_set_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *stream);
+/* The same matrices on demand, without slowing the tracker down: recomputes them, from everything the handle has
+ * consumed since its last reset, into caller-owned double [B][2N][N] buffers (the frames pushed through
+ * rts_otw_insert / rts_otw_push are kept by the handle; after rts_otw_run the caller's live buffer is read again
+ * and must still be valid).  The handle's own state is not touched, so the streams keep running on the pipelined
+ * kernel.  Synchronises `stream`.  What the drop-in classes' .acc_cost / .cost (otw_eran.py:23,27) are made of. */
+int rts_otw_replay_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *stream);
 /* Tuning knob, not semantics: waves per stream workgroup (1, 2, 4 or 8; default 8).  Results are identical.
  * With 8 waves and no dense mirror the library runs its pipelined kernel (the next step's strips are computed
  * beside this step's control work); the environment variable RTS_OTW_SPEC=0, read by rts_otw_create, selects

@@ -2,7 +2,8 @@
 
 Each instance is a batch-of-one BatchedOTW with float64 features (the reference computes in
 float64, otw_eran.py:20-27).  insert() launches the HIP kernel for one frame and reads the
-32-byte state word back, because the reference's insert() is synchronous and returns "stop"."""
+64-byte state word back, because the reference's insert() is synchronous and returns "stop".
+The dense acc_cost / cost matrices of the reference are recomputed only when they are read."""
 import numpy as np
 import torch
 
@@ -28,10 +29,9 @@ class OtwDropIn(object):
         self._eng = BatchedOTW(ref, band, max_run_count, batch=1, variant=self._variant, euclid=euclid,
                                device=device, dtype=torch.float64)
         self._dev = self._eng.device
-        # the reference's dense (2N x N) matrices: mirrored on the device when they fit comfortably
+        # the reference's dense (2N x N) matrices are produced lazily, when .acc_cost / .cost is read (a replay of
+        # the kept live history): insert() / set_live() run on the pipelined kernel and never pay for them
         self._dense = 2 * (2 * ref.shape[1]) * ref.shape[1] * 8 <= self.DENSE_LIMIT_BYTES
-        if self._dense:
-            self._eng.enable_dense()
         self._frame = torch.empty((1, ref.shape[0]), dtype=torch.float64, device=self._dev)
         self._path_is_array = False
         self._reported = nat.RUNNING
@@ -100,8 +100,10 @@ class OtwDropIn(object):
                 "the dense (2N x N) %s of the reference is not kept for a reference this long (it would need "
                 "%.1f GiB); use .bands() for the two live bands the algorithm actually reads"
                 % (which, 2 * (2 * self._ref_host.shape[1]) * self._ref_host.shape[1] * 8 / 2.0 ** 30))
-        torch.cuda.synchronize(self._dev)
-        return (self._eng.dense_acc if which == "acc_cost" else self._eng.dense_cost)[0].cpu().numpy()
+        if getattr(self, "_dense_cache", (None,))[0] != self._eng._version:
+            acc, cost = self._eng.replay_dense()
+            self._dense_cache = (self._eng._version, acc[0].cpu().numpy(), cost[0].cpu().numpy())
+        return self._dense_cache[1 if which == "acc_cost" else 2]
 
     @property
     def acc_cost(self):

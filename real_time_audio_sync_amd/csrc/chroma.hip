@@ -372,8 +372,12 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
     h->smem_frames = sizeof(double2) * 2 * N2 + sizeof(double) * (size_t)kChromaFR * (N2 + 2) +
                      ((2 * N2 >= 3264) ? 0 : sizeof(double) * 3264) + 64;
     h->smem_project = sizeof(double) * ((size_t)kChromaFR * (nb + 1) + 3264) + 64;
+    // per plan, i.e. on the device that is current now (the attribute is per device)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_project_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
         rts_chroma_destroy(h);
         return set_error(RTS_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));

@@ -1731,7 +1731,8 @@ __global__ void otw_append_many_kernel(double *hist, int32_t *hist_len, const vo
                                        const int32_t *n_new, int n_uniform, int n_max, int B, int cap) {
     const int b = blockIdx.x;
     if (b >= B) return;
-    const int nn = n_new ? n_new[b] : n_uniform;
+    int nn = n_new ? n_new[b] : n_uniform;
+    nn = nn < 0 ? 0 : (nn > n_max ? n_max : nn);  // never read a neighbouring stream's frames
     const int base = hist_len[b];
     __syncthreads();
     for (int idx = threadIdx.x; idx < nn * kF; idx += blockDim.x) {
@@ -1764,20 +1765,37 @@ struct rts_otw {
     long long *debug;   // diagnostic builds only
     double *dense_acc, *dense_cost;  // caller-owned, optional
     int spec;           // 1: pipelined kernel (needs 8 waves and no dense mirror); 0: plain kernel
+    int device;         // the HIP device the handle's buffers live on (one handle = one device)
+    const void *attr_fn[8];  // kernel instantiations whose dynamic-LDS limit is already raised on `device`
+    // what the handle has consumed since the last reset, for rts_otw_replay_dense
+    int src_kind;       // 0 nothing, 1 the buffers of the last rts_otw_run, 2 the handle-owned history, 3 mixed
+    const void *run_live;
+    const int32_t *run_len;
+    int run_dtype, run_T, run_mode;
 };
 
 namespace rts {
 
+// The dynamic-LDS limit is a per-device function attribute: remembered per handle (a handle lives on one device),
+// not per process.
+static int ensure_lds_attr(rts_otw *h, const void *fn, size_t smem) {
+    for (int k = 0; k < 8; k++)
+        if (h->attr_fn[k] == fn) return RTS_OK;
+    RTS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    for (int k = 0; k < 8; k++)
+        if (!h->attr_fn[k]) {
+            h->attr_fn[k] = fn;
+            break;
+        }
+    return RTS_OK;
+}
+
 template <int W, int NW, bool DENSE, typename RT, bool SPEC>
-static int launch_advance_d(const OtwArgs &args, int B, hipStream_t s) {
+static int launch_advance_d(rts_otw *h, const OtwArgs &args, int B, hipStream_t s) {
     using LdsT = OtwLds<W, RT>;
     const size_t smem = SPEC ? ((offsetof(LdsT, refw) + 15) & ~(size_t)15) + sizeof(OtwSpecLds<W>) : sizeof(LdsT);
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&otw_advance_kernel<W, NW, DENSE, RT, SPEC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-    }
+    const int rc = ensure_lds_attr(h, reinterpret_cast<const void *>(&otw_advance_kernel<W, NW, DENSE, RT, SPEC>), smem);
+    if (rc != RTS_OK) return rc;
     hipLaunchKernelGGL((otw_advance_kernel<W, NW, DENSE, RT, SPEC>), dim3(B), dim3(64 * NW), smem, s, args);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
@@ -1785,36 +1803,47 @@ static int launch_advance_d(const OtwArgs &args, int B, hipStream_t s) {
 
 // The dense mirror is a separate instantiation so that the default kernel carries none of its code.
 template <int W, int NW>
-static int launch_advance(const OtwArgs &args, int B, hipStream_t s) {
-    if (args.dense_acc) return launch_advance_d<W, NW, true, double, false>(args, B, s);
+static int launch_advance(rts_otw *h, const OtwArgs &args, int B, hipStream_t s) {
+    if (args.dense_acc) return launch_advance_d<W, NW, true, double, false>(h, args, B, s);
     // float32 rings only when both inputs are float32: every value then widens back exactly
     const bool f32 = !args.ref_f64 && !args.live_f64;
     if constexpr (NW >= 8) {
         if (args.spec)
-            return f32 ? launch_advance_d<W, NW, false, float, true>(args, B, s)
-                       : launch_advance_d<W, NW, false, double, true>(args, B, s);
+            return f32 ? launch_advance_d<W, NW, false, float, true>(h, args, B, s)
+                       : launch_advance_d<W, NW, false, double, true>(h, args, B, s);
     }
-    return f32 ? launch_advance_d<W, NW, false, float, false>(args, B, s)
-               : launch_advance_d<W, NW, false, double, false>(args, B, s);
+    return f32 ? launch_advance_d<W, NW, false, float, false>(h, args, B, s)
+               : launch_advance_d<W, NW, false, double, false>(h, args, B, s);
 }
 
 template <int W>
-static int launch_w(const OtwArgs &args, int B, int waves, hipStream_t s) {
+static int launch_w(rts_otw *h, const OtwArgs &args, int B, int waves, hipStream_t s) {
     switch (waves) {
-        case 1: return launch_advance<W, 1>(args, B, s);
-        case 2: return launch_advance<W, 2>(args, B, s);
-        case 4: return launch_advance<W, 4>(args, B, s);
-        case 8: return launch_advance<W, 8>(args, B, s);
+        case 1: return launch_advance<W, 1>(h, args, B, s);
+        case 2: return launch_advance<W, 2>(h, args, B, s);
+        case 4: return launch_advance<W, 4>(h, args, B, s);
+        case 8: return launch_advance<W, 8>(h, args, B, s);
     }
     return set_error(RTS_ERR_INVALID, "waves must be 1, 2, 4 or 8 (got %d)", waves);
 }
 
-static int launch(const rts_otw *h, const OtwArgs &args, hipStream_t s) {
+// A handle belongs to the device that was current at rts_otw_create; driving it with another device current would
+// launch against foreign buffers.
+static int check_device(const rts_otw *h) {
+    int d = -1;
+    RTS_HIP(hipGetDevice(&d));
+    if (d != h->device)
+        return set_error(RTS_ERR_INVALID, "handle was created on device %d but device %d is current "
+                                          "(one process per GPU, or hipSetDevice before the call)", h->device, d);
+    return RTS_OK;
+}
+
+static int launch(rts_otw *h, const OtwArgs &args, hipStream_t s) {
     switch (h->W) {
-        case 64: return launch_w<64>(args, h->B, h->waves, s);
-        case 128: return launch_w<128>(args, h->B, h->waves, s);
-        case 256: return launch_w<256>(args, h->B, h->waves, s);
-        case 512: return launch_w<512>(args, h->B, h->waves, s);
+        case 64: return launch_w<64>(h, args, h->B, h->waves, s);
+        case 128: return launch_w<128>(h, args, h->B, h->waves, s);
+        case 256: return launch_w<256>(h, args, h->B, h->waves, s);
+        case 512: return launch_w<512>(h, args, h->B, h->waves, s);
     }
     return set_error(RTS_ERR_UNSUPPORTED, "no kernel for window %d", h->W);
 }
@@ -1888,6 +1917,10 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     h->live_cap = 2 * N;
     h->path_cap = 3 * N + 8;  // one point per decide(); decides <= row strips + column strips <= 2N + N
     hipError_t e;
+    if ((e = hipGetDevice(&h->device)) != hipSuccess) {
+        free(h);
+        return set_error(RTS_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e));
+    }
     if ((e = hipMalloc((void **)&h->state, sizeof(int32_t) * RTS_STATE_LEN * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->path, sizeof(int32_t) * 2 * (size_t)h->path_cap * B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->bands, sizeof(double) * 2 * (size_t)(c + 1) * B)) != hipSuccess ||
@@ -1900,7 +1933,10 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
         rts_otw_destroy(h);
         return rc;
     }
-    RTS_HIP(hipStreamSynchronize(nullptr));
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) {
+        rts_otw_destroy(h);
+        return set_error(RTS_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    }
     *out = h;
     return RTS_OK;
 }
@@ -1919,7 +1955,9 @@ int rts_otw_destroy(rts_otw *h) {
 int rts_otw_reset(rts_otw *h, void *stream) {
     using namespace rts;
     if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (int rc = check_device(h); rc != RTS_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    h->src_kind = 0;
     hipLaunchKernelGGL(otw_reset_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, h->state, h->B, h->variant);
     RTS_HIP(hipGetLastError());
     RTS_HIP(hipMemsetAsync(h->hist_len, 0, sizeof(int32_t) * (size_t)h->B, s));
@@ -1941,6 +1979,62 @@ int rts_otw_set_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *strea
     h->dense_acc = acc_dev;
     h->dense_cost = cost_dev;
     return rts_otw_reset(h, stream);
+}
+
+int rts_otw_replay_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *stream) {
+    using namespace rts;
+    if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (!acc_dev || !cost_dev) return set_error(RTS_ERR_INVALID, "acc_dev / cost_dev is NULL");
+    if (int rc = check_device(h); rc != RTS_OK) return rc;
+    if (h->src_kind == 3)
+        return set_error(RTS_ERR_UNSUPPORTED, "rts_otw_insert / rts_otw_push after rts_otw_run without a reset: nothing to replay from");
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)h->B * h->live_cap * h->N;
+    const double sentinel = (h->variant == RTS_VARIANT_OTW) ? 1e10 : (double)INFINITY;
+    hipLaunchKernelGGL(otw_fill_kernel, dim3(2048), dim3(256), 0, s, acc_dev, n, sentinel);
+    hipLaunchKernelGGL(otw_fill_kernel, dim3(2048), dim3(256), 0, s, cost_dev, n, -1.0);
+    RTS_HIP(hipGetLastError());
+    if (h->src_kind == 0) return RTS_OK;  // freshly constructed: the matrices are all sentinel (otw_eran.py:23,27)
+    // scratch state so that the handle itself is not disturbed
+    int32_t *state = nullptr, *path = nullptr;
+    double *bands = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&state, sizeof(int32_t) * RTS_STATE_LEN * (size_t)h->B)) != hipSuccess ||
+        (e = hipMalloc((void **)&path, sizeof(int32_t) * 2 * (size_t)h->path_cap * h->B)) != hipSuccess ||
+        (e = hipMalloc((void **)&bands, sizeof(double) * 2 * (size_t)(h->c + 1) * h->B)) != hipSuccess) {
+        if (state) (void)hipFree(state);
+        if (path) (void)hipFree(path);
+        return set_error(RTS_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(otw_reset_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, state, h->B, h->variant);
+    OtwArgs a = base_args(h);
+    a.state = state;
+    a.path = path;
+    a.bands = bands;
+    a.dense_acc = acc_dev;
+    a.dense_cost = cost_dev;
+    if (h->src_kind == 1) {
+        a.live = h->run_live;
+        a.live_len = h->run_len;
+        a.live_stride = h->run_T;
+        a.live_f64 = h->run_dtype == RTS_F64;
+        a.mode = h->run_mode;
+        a.clamp_len = 1;
+    } else {
+        a.live = h->hist;
+        a.live_len = h->hist_len;
+        a.live_stride = h->live_cap;
+        a.live_f64 = 1;
+        a.mode = RTS_MODE_INSERT_LOOP;
+    }
+    int rc = launch(h, a, s);
+    const hipError_t es = hipStreamSynchronize(s);
+    (void)hipFree(state);
+    (void)hipFree(path);
+    (void)hipFree(bands);
+    if (rc != RTS_OK) return rc;
+    if (es != hipSuccess) return set_error(RTS_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
+    return RTS_OK;
 }
 
 int rts_otw_set_waves(rts_otw *h, int waves) {
@@ -1972,6 +2066,12 @@ int rts_otw_run(rts_otw *h, const void *live_dev, int live_dtype, int T_max, con
     a.live_f64 = live_dtype == RTS_F64;
     a.mode = mode;
     a.clamp_len = 1;
+    h->src_kind = 1;
+    h->run_live = live_dev;
+    h->run_len = live_len_dev;
+    h->run_dtype = live_dtype;
+    h->run_T = T_max;
+    h->run_mode = mode;
     return launch(h, a, s);
 }
 
@@ -1981,9 +2081,11 @@ int rts_otw_insert(rts_otw *h, const void *frames_dev, int frames_dtype, const u
     if (!frames_dev) return set_error(RTS_ERR_INVALID, "frames_dev is NULL");
     if (frames_dtype != RTS_F32 && frames_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad frames_dtype %d", frames_dtype);
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = check_device(h); rc != RTS_OK) return rc;
     if (!h->hist) {
         RTS_HIP(hipMalloc((void **)&h->hist, sizeof(double) * kF * (size_t)h->live_cap * h->B));
     }
+    h->src_kind = (h->src_kind == 0 || h->src_kind == 2) ? 2 : 3;
     hipLaunchKernelGGL(otw_append_kernel, dim3(h->B), dim3(64), 0, s, h->hist, h->hist_len, frames_dev,
                        frames_dtype == RTS_F64, active_dev, h->B, h->live_cap);
     RTS_HIP(hipGetLastError());
@@ -2005,9 +2107,11 @@ int rts_otw_push(rts_otw *h, const void *frames_dev, int frames_dtype, int n_max
     if (!frames_dev) return set_error(RTS_ERR_INVALID, "frames_dev is NULL");
     if (frames_dtype != RTS_F32 && frames_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad frames_dtype %d", frames_dtype);
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = check_device(h); rc != RTS_OK) return rc;
     if (!h->hist) {
         RTS_HIP(hipMalloc((void **)&h->hist, sizeof(double) * kF * (size_t)h->live_cap * h->B));
     }
+    h->src_kind = (h->src_kind == 0 || h->src_kind == 2) ? 2 : 3;
     hipLaunchKernelGGL(otw_append_many_kernel, dim3(h->B), dim3(128), 0, s, h->hist, h->hist_len, frames_dev,
                        frames_dtype == RTS_F64, n_new_dev, n_max, n_max, h->B, h->live_cap);
     RTS_HIP(hipGetLastError());

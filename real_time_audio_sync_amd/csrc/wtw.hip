@@ -391,7 +391,8 @@ __global__ void wtw_append_kernel(double *live, int32_t *appended, int32_t *stat
                                   const int32_t *n_new, int n_uniform, int n_max, int B, int N) {
     const int b = blockIdx.x;
     if (b >= B) return;
-    const int nn = n_new ? n_new[b] : n_uniform;
+    int nn = n_new ? n_new[b] : n_uniform;
+    nn = nn < 0 ? 0 : (nn > n_max ? n_max : nn);  // never read a neighbouring stream's columns
     const int base_raw = appended[b];
     const int base = base_raw < N ? base_raw : N;
     const int running = state[(size_t)b * 8 + 3] == RTS_RUNNING;

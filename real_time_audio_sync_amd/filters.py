@@ -43,6 +43,11 @@ def load_wav(path):
         fs = w.getframerate()
         nch = w.getnchannels()
         raw = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    if fs != 22050:
+        # librosa.load(path) would resample to 22 050 Hz here (chroma.py:27, wtw.py:23); its resampler is a
+        # third-party dependency the reference does not pin, so it is not reproduced: refuse instead of drifting
+        raise ValueError("%s is sampled at %d Hz; this build takes 22 050 Hz input only (the reference relies on "
+                         "librosa.load's resampler for other rates -- resample the file first)" % (path, fs))
     x = raw.reshape(-1, nch).astype(np.float32) / np.float32(32768.0)
     y = x.mean(axis=1, dtype=np.float32) if nch > 1 else x[:, 0]
     return np.ascontiguousarray(y, dtype=np.float32), fs

@@ -55,6 +55,7 @@ class BatchedOTW:
         if waves is not None:
             nat.check(nat.lib.rts_otw_set_waves(self._h, int(waves)))
         self._keep = None
+        self._version = 0  # bumped by everything that changes what the handle has consumed
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
@@ -83,6 +84,7 @@ class BatchedOTW:
         """Asynchronous on the current stream.  live_dev: [B][T_max][12]; live_len_dev: int32 [B]."""
         assert live_dev.is_contiguous() and live_dev.shape[0] == self.B and live_dev.shape[2] == 12
         self._keep = (live_dev, live_len_dev)
+        self._version += 1
         nat.check(nat.lib.rts_otw_run(self._h, live_dev.data_ptr(), _np_dtype_code(live_dev.dtype),
                                       int(live_dev.shape[1]), live_len_dev.data_ptr(),
                                       nat.MODE_SET_LIVE if mode == "set_live" else nat.MODE_INSERT_LOOP,
@@ -91,6 +93,7 @@ class BatchedOTW:
     def insert(self, frames_dev, active_dev=None):
         """One frame per stream: frames_dev [B][12]; active_dev optional uint8 [B]."""
         assert frames_dev.is_contiguous() and tuple(frames_dev.shape) == (self.B, 12)
+        self._version += 1
         nat.check(nat.lib.rts_otw_insert(self._h, frames_dev.data_ptr(), _np_dtype_code(frames_dev.dtype),
                                          active_dev.data_ptr() if active_dev is not None else None,
                                          self._stream()))
@@ -98,11 +101,13 @@ class BatchedOTW:
     def push(self, frames_dev, n_new_dev=None):
         """Several frames per stream: frames_dev [B][n_max][12]; n_new_dev optional int32 [B]."""
         assert frames_dev.is_contiguous() and frames_dev.shape[0] == self.B and frames_dev.shape[2] == 12
+        self._version += 1
         nat.check(nat.lib.rts_otw_push(self._h, frames_dev.data_ptr(), _np_dtype_code(frames_dev.dtype),
                                        int(frames_dev.shape[1]), n_new_dev.data_ptr() if n_new_dev is not None else None,
                                        self._stream()))
 
     def reset(self):
+        self._version += 1
         nat.check(nat.lib.rts_otw_reset(self._h, self._stream()))
 
     # ---- results ------------------------------------------------------------------------------
@@ -147,6 +152,15 @@ class BatchedOTW:
         nat.check(nat.lib.rts_otw_set_dense(self._h, self.dense_acc.data_ptr(), self.dense_cost.data_ptr(),
                                             self._stream()))
         return self.dense_acc, self.dense_cost
+
+    def replay_dense(self):
+        """The reference's dense (2N x N) acc_cost / cost matrices (float64 device tensors [B][2N][N]) for
+        everything consumed since the last reset, recomputed on demand by a second pass over the kept frames
+        (rts_otw_replay_dense); the tracker itself never pays for them."""
+        acc = torch.empty((self.B, 2 * self.N, self.N), dtype=torch.float64, device=self.device)
+        cost = torch.empty((self.B, 2 * self.N, self.N), dtype=torch.float64, device=self.device)
+        nat.check(nat.lib.rts_otw_replay_dense(self._h, acc.data_ptr(), cost.data_ptr(), self._stream()))
+        return acc, cost
 
     def set_waves(self, waves):
         nat.check(nat.lib.rts_otw_set_waves(self._h, int(waves)))

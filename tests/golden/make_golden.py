@@ -15,7 +15,11 @@ its small outputs are committed.  What it does:
     on the chroma of the two WAVs the checkout still holds (computed by oracle/chroma_oracle.py,
     since chroma.py itself needs librosa; recorded as *inputs* of the fixture),
   * stores inputs + paths + end state + the two live accumulated-cost bands + sha256 of the dense
-    float64 acc_cost (and cost) matrices.
+    float64 acc_cost (and cost) matrices,
+  * cuts ``create_stft`` out of chroma.py as text (chroma.py:44-65 is pure numpy; the module itself
+    cannot be imported: IPython / librosa / pyaudio are absent), rewrites its three ``/`` -- all with
+    int operands, Python 2 floor division -- to ``//``, and runs it on the two chopin WAVs:
+    stft_golden.npz holds a handful of STFT columns and the sha256 of the whole complex matrix.
 
 Usage:  python tests/golden/make_golden.py      (takes ~1-2 minutes; reference is pure Python)
 """
@@ -113,8 +117,37 @@ def run_otw_like(mods, variant, ref, live, c, mrc, mode, euclid=False):
                 cost_sha=sha(o.cost), cells=int((o.cost != -1).sum()))
 
 
+def make_stft_golden():
+    """chroma.py:44-65 executed from its own text -> stft_golden.npz (direct pin of create_stft)."""
+    src = open(os.path.join(REF, "chroma.py")).read()
+    a = src.index("def create_stft(wav):")
+    b = src.index("def create_chroma(", a)
+    fn_src = src[a:b]
+    assert fn_src.count("/") == 3, "chroma.py:49,53,54 are the only divisions expected"
+    fn_src = fn_src.replace("/", "//")
+    ns = {"np": np, "fft_len": 4096, "hop_size": 2048}  # chroma.py:20-21
+    exec(compile(fn_src, os.path.join(REF, "chroma.py"), "exec"), ns)
+    st = {}
+    for key, fn in (("ref", "chopin_rubinstein_20b.wav"), ("live", "chopin_rachmaninoff_20b.wav")):
+        wav, fs = chroma_oracle.load_wav_mono(os.path.join(REF, "Songs/chopin", fn))  # what librosa.load returns
+        assert fs == 22050 and wav.dtype == np.float32
+        ft = ns["create_stft"](wav)
+        cols = np.array(sorted({0, 1, 2, 47, 100, 200, ft.shape[1] - 2, ft.shape[1] - 1}))
+        st[key + "/shape"] = np.array(ft.shape)
+        st[key + "/cols"] = cols
+        st[key + "/stft_cols"] = np.ascontiguousarray(ft[:, cols])
+        st[key + "/sha"] = np.asarray(sha(ft))
+        st[key + "/power_sum"] = (np.abs(ft) ** 2).sum(axis=0)  # one float64 per frame: a whole-matrix value check
+        print("%-28s create_stft -> %s sha %s" % ("stft_" + key, ft.shape, sha(ft)[:16]))
+    np.savez_compressed(os.path.join(HERE, "stft_golden.npz"), **st)
+
+
 def main():
     np.int = int  # dtw.py:17
+    if "--only-stft" in sys.argv:
+        make_stft_golden()
+        return
+    make_stft_golden()
     mods = {n: load_reference_module(n) for n in ("otw_eran", "livenote", "livenote_v2", "dtw")}
     mods["wtw"] = load_reference_module(
         "wtw", drop_imports=("matplotlib", "IPython", "librosa", "pyaudio", "plt.rcParams"))

@@ -119,3 +119,22 @@ def test_other_hop_and_fft_sizes(mods):
     from real_time_audio_sync_amd import _native as nat
     with pytest.raises(nat.RtsyncError):
         chroma.ChromaPlan(8192, 2048, 22050)   # 8192-point frames do not fit the LDS-resident FFT
+
+
+def test_create_stft_against_reference_columns(mods, chopin_audio):
+    """Direct pin of a1: STFT columns and per-frame power sums that the reference's own create_stft
+    (chroma.py:44-65, executed from its text by tests/golden/make_golden.py) produced for the chopin pair,
+    against the HIP FFT at the tolerance stated at the top of this file."""
+    import os
+    from conftest import GOLDEN
+    chroma, _ = mods
+    g = np.load(os.path.join(GOLDEN, "stft_golden.npz"))
+    for key in ("ref", "live"):
+        ft = chroma.create_stft(chopin_audio[key])
+        assert ft.shape == tuple(g[key + "/shape"])
+        want = g[key + "/stft_cols"]
+        got = ft[:, g[key + "/cols"]]
+        scale = np.abs(want).max(axis=0, keepdims=True)
+        assert (np.abs(got - want) <= STFT_RTOL * scale).all(), key
+        ps = (np.abs(ft) ** 2).sum(axis=0)
+        assert np.abs(ps - g[key + "/power_sum"]).max() <= 1e-11 * g[key + "/power_sum"].max(), key

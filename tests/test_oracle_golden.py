@@ -4,6 +4,7 @@
 Bit-exactness claimed here: alignment-path indices, end state, the two live accumulated-cost bands
 and the sha256 of the whole dense float64 acc_cost / cost matrices."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -157,3 +158,47 @@ def test_chroma_oracle_shapes_and_norm(chopin_audio, otw_golden):
     assert col.shape == (12, 1) or col.shape == (12,)
     d = chroma_oracle.wav_to_chroma_diff(chopin_audio["ref"][:60000])
     assert d.shape[0] == 12 and (d >= 0).all()
+
+
+def test_create_stft_pinned_by_the_reference(chopin_audio):
+    """chroma.py:44-65 was executed from its own text on the two chopin WAVs (tests/golden/make_golden.py::
+    make_stft_golden); the numpy restatement in oracle/chroma_oracle.py reproduces its complex STFT bit for bit:
+    sha256 of the whole (2049, M) matrix, the stored columns, the per-frame power sums."""
+    import hashlib
+    from conftest import GOLDEN
+    from oracle import chroma_oracle as co
+    g = np.load(os.path.join(GOLDEN, "stft_golden.npz"))
+    for key in ("ref", "live"):
+        ft = co.create_stft(chopin_audio[key])
+        assert tuple(g[key + "/shape"]) == ft.shape and ft.dtype == np.complex128
+        assert hashlib.sha256(np.ascontiguousarray(ft).tobytes()).hexdigest() == str(g[key + "/sha"]), key
+        assert np.array_equal(ft[:, g[key + "/cols"]], g[key + "/stft_cols"])
+        assert np.array_equal((np.abs(ft) ** 2).sum(axis=0), g[key + "/power_sum"])
+
+
+def test_numpy_restatement_matches_reference_goldens(otw_golden):
+    """oracle/otw_numpy.py (the "numpy otw_eran.py path" bench.py times as a cpu_baseline leg) against every
+    OnlineTimeWarping insert-loop case the reference's own code produced: path, end state, both live bands and the
+    sha256 of the dense float64 acc_cost / cost matrices, bit for bit."""
+    from oracle import otw_numpy
+    g = otw_golden
+    done = 0
+    for meta in g["cases"]:
+        case = parse_case(meta)
+        if case["variant"] != "otw" or case["mode"] != "insert" or case["c"] > 64:
+            continue  # c = 500 cases take minutes in pure Python; the c <= 64 ones cover every branch
+        cid = case["cid"]
+        ref = g[case["group"] + "/ref"].astype(np.float64)
+        live = g[case["group"] + "/live"].astype(np.float64)
+        o = otw_numpy.NumpyOTW(ref, case["c"], case["mrc"])
+        consumed = o.run(live)
+        assert np.array_equal(np.array(o.path, dtype=np.int32).reshape(-1, 2), g[cid + "/path"]), cid
+        assert (o.t, o.j, consumed) == (int(g[cid + "/t"]), int(g[cid + "/j"]), int(g[cid + "/consumed"])), cid
+        assert (o.status == otw_numpy.STOP_REF_END) == bool(g[cid + "/stopped"]), cid
+        assert o.run_count == int(g[cid + "/run_count"]), cid
+        rb, cb = o.bands()
+        assert np.array_equal(rb, g[cid + "/row_band"], equal_nan=True), cid
+        assert np.array_equal(cb, g[cid + "/col_band"], equal_nan=True), cid
+        assert sha(o.acc) == str(g[cid + "/acc_sha"]) and sha(o.cost) == str(g[cid + "/cost_sha"]), cid
+        done += 1
+    assert done >= 6

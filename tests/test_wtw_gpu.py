@@ -196,3 +196,31 @@ def test_wtw_argument_errors():
         BatchedWTW(ref, 20, 0)      # dtw_hop_size < hop_size: the reference would loop forever
     with pytest.raises(nat.RtsyncError):
         BatchedWTW(ref, 16385, 10)  # beyond the supported window
+
+
+def test_known_answer_through_path_file_and_metric(chopin_audio, tmp_path):
+    """SURVEY 8(f1)+(f2) on device output: the WTW path the HIP kernels produce for the chopin pair, written with
+    pathfile.write_path_file exactly like test_simple.py:183-185 writes it, is byte-identical to the reference's
+    Songs/chopin/tests/wtw_test_20b.txt; read back (tests.py:20-27) and scored with the accuracy metric
+    (tests.py:29-137) it gives the numbers the reference's own test_simple class printed for that file
+    (tests/golden/eval_golden.json, made by executing that class)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from real_time_audio_sync_amd import evaluate, pathfile
+    from real_time_audio_sync_amd.wtw import WTW
+    wtw = WTW.from_samples(chopin_audio["ref"], PARAMS, {'chroma': False})
+    for buf in np.array_split(chopin_audio["live"], 4096):
+        if wtw.insert(buf.tolist()) == "stop":
+            break
+    f = tmp_path / "wtw_test.txt"
+    pathfile.write_path_file(str(f), wtw.path)
+    assert f.read_bytes() == open(os.path.join(GOLDEN, "wtw_test_20b.txt"), "rb").read()
+    path = pathfile.read_path_file(str(f), header_lines=0)
+    ev = evaluate.AlignmentError(os.path.join(GOLDEN, "chopin_rubinstein_20b.csv"),
+                                 os.path.join(GOLDEN, "chopin_rachmaninoff_20b.csv"), path)
+    gold = json.load(open(os.path.join(GOLDEN, "eval_golden.json")))["wtw_known_answer"]
+    st = ev.stats()
+    lines = [st["pct_off_beats"][t] for t in (1, 3, 5, 10)] + [st["pct_off_seconds"][t] for t in (1, 3, 5, 10)]
+    assert lines == gold["percent_lines"]          # exact float equality
+    assert ev.get_error(verbose=False) == gold["returned"]

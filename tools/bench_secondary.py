@@ -54,16 +54,16 @@ def main():
         r = synth.synth_ref(n, seed=n)
         l = synth.synth_live(r, seed=n + 1, max_frames=n)
         a, b = frames_tensor(l, dev, torch.float32), frames_tensor(r, dev, torch.float32)
-        t = timed(lambda: dtw.dtw_batch(a, b))
+        t = timed(lambda: dtw.dtw_batch(a, b, want_back=False))
         cells = a.shape[0] * b.shape[0]
-        out.append(dict(kernel="dtw_cost+dtw_dp", M=int(a.shape[0]), N=int(b.shape[0]), pairs=1, seconds=t,
-                        cells_per_s=cells / t, algorithmic_bytes=cells * 17,
-                        note="8 B cost + 8 B acc + 1 B back-pointer per cell; one pair = one workgroup, barrier per anti-diagonal"))
+        out.append(dict(kernel="rts_dtw (cost + strip DP + backtrack)", M=int(a.shape[0]), N=int(b.shape[0]), pairs=1,
+                        seconds=t, cells_per_s=cells / t, algorithmic_bytes=cells * 16.25,
+                        note="8 B cost + 8 B acc + 2 bits of step code per cell; strips of 64 rows pipelined over waves / workgroups"))
         if n == 322:
             ab = a.unsqueeze(0).repeat(256, 1, 1).contiguous()
-            t = timed(lambda: dtw.dtw_batch(ab, b))
-            out.append(dict(kernel="dtw_cost+dtw_dp", M=int(a.shape[0]), N=int(b.shape[0]), pairs=256, seconds=t,
-                            cells_per_s=256 * cells / t, hbm_GBps=256 * cells * 17 / t / 1e9))
+            t = timed(lambda: dtw.dtw_batch(ab, b, want_back=False))
+            out.append(dict(kernel="rts_dtw (cost + strip DP + backtrack)", M=int(a.shape[0]), N=int(b.shape[0]), pairs=256,
+                            seconds=t, cells_per_s=256 * cells / t, hbm_GBps=256 * cells * 16.25 / t / 1e9))
 
     # ---- WTW: 64 streams, W=100/hop=50 (wtw_live.py's setting) on a 2200-frame reference
     ref, lives = synth.synth_batch(2200, 64, seed=3)
@@ -96,12 +96,52 @@ def main():
         eng5.push(c5, precheck=True)
     t = timed(run5, reps=3, warm=1)
     s5 = eng5.state()
-    out.append(dict(kernel="wtw_advance_kernel(HBM-resident window)", streams=1, W=10000, hop=5000, windows=s5["windows"],
-                    seconds=t, cells_per_s=s5["cells"] / t, frames_per_s=s5["chroma_ptr"] / t,
-                    algorithmic_bytes=s5["cells"] * 1,
-                    note="1 B back-pointer per cell is the only W^2 HBM stream; single workgroup, 19 999 barriers per window"))
-    # ---- live use: one frame per stream per launch (rts_otw_insert), 64 streams, c = 500
+    out.append(dict(kernel="wtw_big_dp_kernel + wtw_big_ctl_kernel (strip DP over many workgroups)", streams=1, W=10000,
+                    hop=5000, windows=s5["windows"], seconds=t, seconds_per_window=t / max(1, s5["windows"]),
+                    cells_per_s=s5["cells"] / t, frames_per_s=s5["chroma_ptr"] / t,
+                    algorithmic_bytes_per_window=2 * 10000 * 10000 + 2 * 12 * 4 * 10000,
+                    note="SURVEY 8(d) figure 2 W^2 + 96 W bytes per window; the kernel itself writes 2 bits per cell"))
+    # ---- BASELINE configs[1]: single-stream OTW c=500, N=2200 -- batched engine with B=1, and the drop-in class
     from real_time_audio_sync_amd.otw_batch import BatchedOTW
+    from real_time_audio_sync_amd.otw_eran import OnlineTimeWarping
+    ref1 = synth.synth_ref(2200, seed=1000)
+    live1 = synth.synth_live(ref1, seed=1001)
+    for dt_name, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+        e1 = BatchedOTW(ref1, 500, 3, batch=1, dtype=tdt)
+        lv1, ln1 = e1.pack([live1])
+        t = timed(lambda: e1.run(lv1, ln1))
+        fr = int(e1.states()[0, 8])
+        out.append(dict(kernel="rts_otw_run B=1 (configs[1])", features=dt_name, frames=fr, seconds=t, frames_per_s=fr / t))
+        e1.close()
+    for dt_name, tdt in (("f64", torch.float64),):
+        refb, livesb = synth.synth_batch(2200, 64, seed=1000)
+        e64 = BatchedOTW(refb, 500, 3, batch=64, dtype=tdt)
+        lvb, lnb = e64.pack(livesb)
+        t = timed(lambda: e64.run(lvb, lnb))
+        fr = int(e64.states()[:, 8].sum())
+        out.append(dict(kernel="rts_otw_run B=64", features=dt_name, frames=fr, seconds=t, frames_per_s=fr / t,
+                        note="float64 features in HBM (what wav_to_chroma produces): the <double> ring instantiation"))
+        e64.close()
+    o1 = OnlineTimeWarping(ref1, {'c': 500, 'max_run_count': 3})
+    t0 = time.perf_counter()
+    n1 = 0
+    for i in range(live1.shape[1]):
+        n1 += 1
+        if o1.insert(live1[:, i]) == "stop":
+            break
+    wall = time.perf_counter() - t0
+    out.append(dict(kernel="OnlineTimeWarping.insert loop (drop-in class, one launch + state read-back per frame)",
+                    frames=n1, seconds=wall, frames_per_s=n1 / wall, us_per_insert=wall / n1 * 1e6,
+                    note="host wall time; the reference's own class does 262 frames/s at this setting (BASELINE.md 3a)"))
+    o2 = OnlineTimeWarping(ref1, {'c': 500, 'max_run_count': 3})
+    t = timed(lambda: o2.set_live(live1), reps=3, warm=1)
+    out.append(dict(kernel="OnlineTimeWarping.set_live (drop-in class, one launch)", frames=int(live1.shape[1]), seconds=t,
+                    frames_per_s=live1.shape[1] / t))
+    t0 = time.perf_counter()
+    acc = o2.acc_cost
+    out.append(dict(kernel="OnlineTimeWarping.acc_cost (lazy dense replay + D2H of 2N x N float64)", seconds=time.perf_counter() - t0,
+                    bytes=int(acc.nbytes)))
+    # ---- live use: one frame per stream per launch (rts_otw_insert), 64 streams, c = 500
     ref6, lives6 = synth.synth_batch(2200, 64, seed=1000)
     eng6 = BatchedOTW(ref6, 500, 3, batch=64, dtype=torch.float64)
     T6 = min(l.shape[1] for l in lives6)
