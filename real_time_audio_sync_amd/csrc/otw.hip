@@ -232,7 +232,7 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
                                             long long *rounds_acc = nullptr, bool prev0_xin = false, double alt_xin = 0.0,
                                             int *alt_ok = nullptr) {
     constexpr int L = W / 64;
-    constexpr int LOG_L = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : 3;
+    constexpr int LOG_L = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
     const double inf = INFINITY;
     // cell (lane, m) sits at band position q + L*lane with q = k1 + m wave-uniform, i.e. at LDS slot
     // (q mod L)*65 + ((q / L + lane) mod 64); slot[m] addresses position k - 1 of cell m
@@ -1650,10 +1650,14 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
         const int fl = S.plan_flags[sp];  // pipelined kernel: which buffer of each pair ended up holding the band
         const double *Rf = (SPEC && (fl & kPlanRi)) ? SP.ShR : S.R, *Cf = (SPEC && (fl & kPlanCi)) ? SP.ShC : S.C;
+        // set_live that ran out of live frames stops with t one past the last frame (otw_eran.py:113-116): row t was
+        // never evaluated and reads as the matrix's initial value
+        const bool row_missing = (t_state >= e.live_len) && (t_state <= a.live_cap - 1);
+        const double sentinel = (e.variant == RTS_VARIANT_OTW) ? 1e10 : (double)INFINITY;
         for (int i = tid; i <= c; i += NT) {
             const int y = je - c + i, x = te - c + i;
-            bb[i] = (y >= 0) ? Rf[swz<W>(y)] : qnan;
-            bb[(c + 1) + i] = (x >= 0 && x <= t_state) ? Cf[swz<W>(x)] : qnan;
+            bb[i] = (y >= 0) ? (row_missing ? sentinel : Rf[swz<W>(y)]) : qnan;
+            bb[(c + 1) + i] = (x >= 0 && x <= t_state) ? ((row_missing && x == t_state) ? sentinel : Cf[swz<W>(x)]) : qnan;
         }
     }
 #if defined(RTS_OTW_STAMPS) && RTS_OTW_STAMPS == 1
@@ -1839,11 +1843,17 @@ static int check_device(const rts_otw *h) {
 }
 
 static int launch(rts_otw *h, const OtwArgs &args, hipStream_t s) {
+    if (h->W == 1024 && (args.ref_f64 || args.live_f64 || args.dense_acc))
+        return set_error(RTS_ERR_UNSUPPORTED,
+                         "band widths above 500 (c=%d) keep a 1024-frame live ring in LDS, which fits only as float32: "
+                         "pass float32 reference and live features to rts_otw_run (rts_otw_insert / rts_otw_push and "
+                         "the dense mirror keep float64 and stop at c = 500)", h->c);
     switch (h->W) {
         case 64: return launch_w<64>(h, args, h->B, h->waves, s);
         case 128: return launch_w<128>(h, args, h->B, h->waves, s);
         case 256: return launch_w<256>(h, args, h->B, h->waves, s);
         case 512: return launch_w<512>(h, args, h->B, h->waves, s);
+        case 1024: return launch_w<1024>(h, args, h->B, h->waves, s);  // c up to 1012: one workgroup per CU
     }
     return set_error(RTS_ERR_UNSUPPORTED, "no kernel for window %d", h->W);
 }
@@ -1884,8 +1894,8 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     if (N < 1 || B < 1) return set_error(RTS_ERR_INVALID, "N and B must be >= 1 (got N=%d B=%d)", N, B);
     if (ref_dtype != RTS_F32 && ref_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad ref_dtype %d", ref_dtype);
     if (c < 1) return set_error(RTS_ERR_INVALID, "c must be >= 1 (got %d)", c);
-    if (c > 500)
-        return set_error(RTS_ERR_UNSUPPORTED, "band width c=%d exceeds the 500 cells the LDS-resident kernel holds", c);
+    if (c > 1012)
+        return set_error(RTS_ERR_UNSUPPORTED, "band width c=%d exceeds the 1012 cells the LDS-resident kernel holds", c);
     if (max_run_count < 1) return set_error(RTS_ERR_INVALID, "max_run_count must be >= 1");
     if (variant < RTS_VARIANT_OTW || variant > RTS_VARIANT_LIVENOTE_V2)
         return set_error(RTS_ERR_INVALID, "bad variant %d", variant);

@@ -213,6 +213,13 @@ def main():
     add_case("F_otw_stop_c20_insert", "otw", refF, liveF, 20, 3, "insert")
     add_case("F_otw_stop_c20_set_live", "otw", refF, liveF, 20, 3, "set_live")
 
+    # ---- H: band wider than 500 cells (the 1024-cell window of the kernel) ------------------------
+    refH = synth.synth_ref(1300, seed=81)
+    liveH = synth.synth_live(refH, seed=82)
+    out["H/ref"], out["H/live"] = refH.astype(np.float32), liveH.astype(np.float32)
+    add_case("H_otw_c800_insert", "otw", refH, liveH, 800, 3, "insert")
+    add_case("H_livenote_v2_c1000_insert", "livenote_v2", refH, liveH, 1000, 3, "insert")
+
     # ---- chopin pair (real audio; chroma from the numpy oracle -- chroma.py needs librosa) ---
     wav_r, _ = chroma_oracle.load_wav_mono(os.path.join(REF, "Songs/chopin/chopin_rubinstein_20b.wav"))
     wav_l, _ = chroma_oracle.load_wav_mono(os.path.join(REF, "Songs/chopin/chopin_rachmaninoff_20b.wav"))

@@ -50,6 +50,8 @@ def test_golden_cases(gpu, otw_golden, dtype):
         case = parse_case(meta)
         if dtype == "f32" and case["group"] == "G":
             continue  # real chroma is not float32-exact
+        if dtype == "f64" and case["c"] > 500:
+            continue  # bands wider than 500 cells need the float32 rings (include/rtsync.h, rts_otw_create)
         ref = g[case["group"] + "/ref"].astype(np.float64)
         live = g[case["group"] + "/live"].astype(np.float64)
         tdt = torch.float64 if dtype == "f64" else torch.float32
@@ -232,7 +234,7 @@ def test_argument_errors(gpu):
     nat, ob, synth = gpu["nat"], gpu["ob"], gpu["synth"]
     ref = synth.synth_ref(50, seed=1)
     with pytest.raises(nat.RtsyncError):
-        ob.BatchedOTW(ref, 501, 3)   # band too wide for the LDS-resident kernel
+        ob.BatchedOTW(ref, 1013, 3)   # band too wide for the LDS-resident kernel
     with pytest.raises(nat.RtsyncError):
         ob.BatchedOTW(ref, 0, 3)
     with pytest.raises(nat.RtsyncError):
@@ -309,3 +311,47 @@ def test_soak_medium_and_wide_bands(gpu):
     the kernel changes; the logs kept from round 1 cover 2 050 configurations.)"""
     import otw_soak
     assert otw_soak.run(120, seed=31, verbose=False) >= 120
+
+
+def test_bands_wider_than_500_cells(gpu):
+    """500 < c <= 1012 run on the 1024-cell window (float32 feature rings, rts_otw_run only): every variant against the
+    dense oracle -- path, end state, both live bands -- plus the refusals the header documents.  (The reference-made
+    goldens H_otw_c800 / H_livenote_v2_c1000 are covered by test_golden_cases.)"""
+    import oracle
+    from real_time_audio_sync_amd import _native as nat, synth
+    ob = gpu["ob"]
+    vmap = {"otw": oracle.OTW, "livenote": oracle.LIVENOTE, "livenote_v2": oracle.LIVENOTE_V2}
+    checked = 0
+    for c, n_ref, variant, mode in ((501, 700, "otw", "insert"), (640, 1500, "livenote", "set_live"),
+                                    (900, 1000, "livenote_v2", "insert"), (1012, 1600, "otw", "insert"),
+                                    (1012, 1100, "otw", "set_live")):
+        ref, lives = synth.synth_batch(n_ref, 3, seed=700 + c)
+        lives[1] = lives[1][:, : max(5, lives[1].shape[1] // 2)]
+        eng = ob.BatchedOTW(ref, c, 3, batch=3, variant=variant, dtype=torch.float32)
+        lv, ln = eng.pack(lives)
+        eng.run(lv, ln, mode=mode)
+        for b, live in enumerate(lives):
+            o = oracle.OtwOracle(ref, c, 3, vmap[variant])
+            if mode == "set_live":
+                o.set_live(live)
+            else:
+                o.run(live)
+            st, so = eng.state(b), o.state
+            tag = (c, variant, mode, b)
+            assert np.array_equal(eng.path(b), o.path), tag
+            assert (st["t"], st["j"], st["run_count"], st["direction"]) == (so["t"], so["j"], so["run_count"], so["direction"]), tag
+            rb, cb = eng.bands(b)
+            orb, ocb = o.bands()
+            assert np.array_equal(rb, orb, equal_nan=True) and np.array_equal(cb, ocb, equal_nan=True), tag
+            checked += 1
+        eng.close()
+    assert checked == 15
+    # float64 features do not fit the 1024-frame ring: refused with a message, not computed wrongly
+    ref, lives = synth.synth_batch(700, 1, seed=5)
+    eng = ob.BatchedOTW(ref, 600, 3, batch=1, dtype=torch.float64)
+    lv, ln = eng.pack(lives, dtype=torch.float64)
+    with pytest.raises(nat.RtsyncError, match="float32"):
+        eng.run(lv, ln)
+    eng.close()
+    with pytest.raises(nat.RtsyncError):
+        ob.BatchedOTW(ref, 1013, 3, batch=1, dtype=torch.float32)
