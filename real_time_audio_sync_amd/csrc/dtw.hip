@@ -8,7 +8,8 @@
 //                         single long pair spreads over many CUs and a batch of short pairs fills the chip.
 //                         Every cell does the reference's three float64 adds and first-minimum argmin
 //                         (dtw.py:35-40): acc_cost is bit-identical to the serial double loop.
-//   dtw_backtrack_kernel  dtw.py:43-52 over the packed step codes, one wave per pair.
+//   dtw_hops_kernel /     dtw.py:43-52 over the packed step codes: the columns at which the path crosses the strip
+//   dtw_segment_kernel    boundaries (one dependent load per strip), then every strip's segment walked by its own wave.
 //   dtw_back_decode_kernel optional: the reference's `back` matrix as int8 [M][N].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,6 +34,8 @@ struct DtwArgs {
     int M, N, a_f64, b_f64;
     uint32_t *codes;           // [B][codes_words]
     unsigned long long *bnd;   // [B][n_strips][N]
+    int32_t *entb;             // [B][n_strips][N]
+    int32_t *cross, *lens;     // [B][n_strips]
     int32_t *err;
     int n_rg;
 };
@@ -78,28 +81,26 @@ __global__ void __launch_bounds__(512) dtw_sdp_kernel(DtwArgs g) {
     pb.ldD = g.N;
     pb.codes = g.codes + (size_t)pair * sdp::codes_words(g.M, g.N);
     pb.bnd = g.bnd + (size_t)pair * sdp::n_strips(g.M) * g.N;
+    pb.entb = g.entb + (size_t)pair * sdp::n_strips(g.M) * g.N;
     pb.err = g.err;
     for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x) sdp::run_rowgroup<sdp::DtwPolicy, true>(pb, rg, g.n_rg, NW, dtw_smem);
 }
 
-__global__ void __launch_bounds__(64) dtw_backtrack_kernel(DtwArgs g) {
+__global__ void __launch_bounds__(64) dtw_hops_kernel(DtwArgs g) {
     __shared__ uint32_t win[2 * sdp::kBtChunks * 64];
-    const int pair = blockIdx.x, lane = threadIdx.x;
-    const int M = g.M, N = g.N;
-    int32_t *path = g.path + (size_t)pair * (M + N) * 2;
-    const uint32_t *codes = g.codes + (size_t)pair * sdp::codes_words(M, N);
-    const int len = sdp::backtrack(codes, M, N, path, M + N, win);
-    __syncthreads();
-    for (int p = lane; p < len / 2; p += 64) {  // path.reverse()
-        const int q = len - 1 - p;
-        const int x0 = path[2 * p], y0 = path[2 * p + 1];
-        const int x1 = path[2 * q], y1 = path[2 * q + 1];
-        path[2 * p] = x1;
-        path[2 * p + 1] = y1;
-        path[2 * q] = x0;
-        path[2 * q + 1] = y0;
-    }
-    if (lane == 0) g.path_len[pair] = (*g.err != 0) ? -1 : len;
+    const int pair = blockIdx.x, S = sdp::n_strips(g.M);
+    sdp::path_hops(g.codes + (size_t)pair * sdp::codes_words(g.M, g.N), g.entb + (size_t)pair * S * g.N, g.M, g.N,
+                   g.cross + (size_t)pair * S, win);
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(64) dtw_segment_kernel(DtwArgs g) {
+    __shared__ uint32_t win[2 * sdp::kBtChunks * 64];
+    const int pair = blockIdx.y, s = blockIdx.x, S = sdp::n_strips(g.M);
+    int32_t *path = g.path + (size_t)pair * (g.M + g.N) * 2;
+    sdp::path_segment(g.codes + (size_t)pair * sdp::codes_words(g.M, g.N), g.M, g.N, s, g.cross + (size_t)pair * S,
+                      g.lens + (size_t)pair * S, PASS, path, g.path_len + pair, win);
+    if (PASS == 1 && s == 0 && threadIdx.x == 0 && *g.err != 0) g.path_len[pair] = -1;
 }
 
 __global__ void __launch_bounds__(256) dtw_back_decode_kernel(DtwArgs g) {
@@ -130,8 +131,9 @@ int rts_dtw_workspace_bytes(int M, int N, int B, size_t *bytes) {
     using namespace rts;
     if (!bytes) return set_error(RTS_ERR_INVALID, "bytes is NULL");
     if (M < 1 || N < 1 || B < 1) return set_error(RTS_ERR_INVALID, "M, N, B must be >= 1");
-    *bytes = 256 + align256(sizeof(unsigned long long) * (size_t)B * sdp::n_strips(M) * N) +
-             align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N));
+    const size_t strips = (size_t)B * sdp::n_strips(M);
+    *bytes = 256 + align256(sizeof(unsigned long long) * strips * N) + align256(sizeof(int32_t) * strips * N) +
+             2 * align256(sizeof(int32_t) * strips) + align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N));
     return RTS_OK;
 }
 
@@ -176,8 +178,18 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
     g.a_f64 = a_dtype == RTS_F64;
     g.b_f64 = b_dtype == RTS_F64;
     g.err = reinterpret_cast<int32_t *>(ws);
-    g.bnd = reinterpret_cast<unsigned long long *>(ws + 256);
-    g.codes = reinterpret_cast<uint32_t *>(ws + 256 + align256(sizeof(unsigned long long) * (size_t)B * strips * N));
+    {
+        unsigned char *p = ws + 256;
+        g.bnd = reinterpret_cast<unsigned long long *>(p);
+        p += align256(sizeof(unsigned long long) * (size_t)B * strips * N);
+        g.entb = reinterpret_cast<int32_t *>(p);
+        p += align256(sizeof(int32_t) * (size_t)B * strips * N);
+        g.cross = reinterpret_cast<int32_t *>(p);
+        p += align256(sizeof(int32_t) * (size_t)B * strips);
+        g.lens = reinterpret_cast<int32_t *>(p);
+        p += align256(sizeof(int32_t) * (size_t)B * strips);
+        g.codes = reinterpret_cast<uint32_t *>(p);
+    }
     g.n_rg = n_rg;
     RTS_HIP(hipMemsetAsync(g.err, 0, 16, s));
     if (n_rg > 1) RTS_HIP(hipMemsetD32Async((hipDeviceptr_t)g.bnd, (int)sdp::kSentinel32, (size_t)2 * B * strips * N, s));
@@ -198,7 +210,9 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(dtw_sdp_kernel, dim3(G, B), dim3(64 * NW), smem, s, g);
     RTS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(dtw_backtrack_kernel, dim3(B), dim3(64), 0, s, g);
+    hipLaunchKernelGGL(dtw_hops_kernel, dim3(B), dim3(64), 0, s, g);
+    hipLaunchKernelGGL((dtw_segment_kernel<0>), dim3(strips, B), dim3(64), 0, s, g);
+    hipLaunchKernelGGL((dtw_segment_kernel<1>), dim3(strips, B), dim3(64), 0, s, g);
     RTS_HIP(hipGetLastError());
     if (back_dev) {
         hipLaunchKernelGGL(dtw_back_decode_kernel, dim3((N + 255) / 256, M, B), dim3(256), 0, s, g);

@@ -67,6 +67,8 @@ struct Problem {
     long long ldD;
     uint32_t *codes;       // [n_strips][n_chunks][64] packed step codes
     unsigned long long *bnd;  // [n_rowgroups][N] bottom rows handed between row groups (sentinel-filled)
+    int32_t *entb;         // [n_strips][N]: for every cell of a strip's bottom row, the column at which its best path
+                           // entered the strip from the row above (what lets the backtrack hop strip to strip)
     int32_t *err;          // set to 1 if a poll ran into its bound (never expected)
 };
 
@@ -97,6 +99,10 @@ __device__ __forceinline__ double shr1(double v, double lane0) {
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), __double2loint(v), 0x138, 0xf, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), __double2hiint(v), 0x138, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int shr1_i(int v, int lane0) {
+    return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false);
 }
 
 __device__ __forceinline__ double readlane_d(double v, int src_lane) {
@@ -277,6 +283,7 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
     lds_barrier();
 
     double prev = 0.0, upprev = 0.0;
+    int ent = 0, ent_upprev = 0;  // entry column (see Problem::entb) of my previous cell / of the cell diagonally above it
     int yslot = (lane == 0) ? 0 : YR - lane;  // ring slot of column 16m - lane at m = 0
     unsigned long long next_bits = kSentinel;
     bool dead = false;
@@ -311,6 +318,7 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
             const double *ybase = yring + (size_t)yslot * kYRec;
             uint32_t codes = 0;
             double collect = 0.0;  // lane q: my lane 63's value of step q (bottom row, column 16m + q - 63)
+            int ecollect = 0;      // the same for its entry column
 
             // 16 branch-free steps.  FIRST: this strip holds matrix row 0 (lane 0); COL0: some lane is at column 0.
             auto steps = [&](auto first_c, auto col0_c) {
@@ -343,12 +351,20 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
                     prev = dv;
                     codes |= (uint32_t)code << (2 * q);
                     asm("" : "+v"(codes));  // materialise now: do not keep 48 lane masks alive
+                    // where did this cell's best path enter the strip?  Lane 0's upper neighbours are in the row above:
+                    // the entry column is that neighbour's own column (16m + q for "up", one less for "diagonal", which is
+                    // exactly what lane 0 received as ent_up one step earlier)
+                    const int ent_up = shr1_i(ent, kChunk * m + q);
+                    ent = (code == kLeft) ? ent : ((code == kUp) ? ent_up : ent_upprev);
+                    ent_upprev = ent_up;
                     {
                         const int lo = __builtin_amdgcn_readlane(__double2loint(dv), 63);
                         const int hi = __builtin_amdgcn_readlane(__double2hiint(dv), 63);
+                        const int el = __builtin_amdgcn_readlane(ent, 63);
                         int clo = __double2loint(collect), chi = __double2hiint(collect);
                         asm("v_writelane_b32 %0, %1, %2" : "+v"(clo) : "s"(lo), "n"(q));
                         asm("v_writelane_b32 %0, %1, %2" : "+v"(chi) : "s"(hi), "n"(q));
+                        asm("v_writelane_b32 %0, %1, %2" : "+v"(ecollect) : "s"(el), "n"(q));
                         collect = __hiloint2double(chi, clo);
                     }
                     if (STAGE) stage_w[q * kStageLd + lane] = dv;
@@ -377,8 +393,10 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
                 const int col = kChunk * m - 63 + lane;
                 if (lane < kChunk) {
                     bring_w[col & (kBRing - 1)] = collect;
-                    if (to_hbm && col >= 0 && col < N)
-                        store_sc1(bnd_out + col, (unsigned long long)__double_as_longlong(collect));
+                    if (col >= 0 && col < N) {
+                        pb.entb[(size_t)strip * N + col] = ecollect;
+                        if (to_hbm) store_sc1(bnd_out + col, (unsigned long long)__double_as_longlong(collect));
+                    }
                 }
             }
             if (STAGE) {
@@ -399,81 +417,139 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
     }
 }
 
-// ---- backtrack over the packed, skewed step codes: one wave ----------------------------------------------------
-// Walks from (M-1, N-1) to (0, 0) and writes the visited points, in walk order (i.e. reversed), as (i, j)
-// pairs to `rev`; returns the number of points.  The walk is a uniform (scalar) loop: the position lives in
-// SGPRs, every lane keeps the code word of ITS row for the current 16-step chunk in a register and the step code
-// is one v_readlane away, so no step waits for a memory round trip.  A window of kBtChunks chunks of the current
-// strip is staged in LDS (`win`: [2][kBtChunks][64] dwords); the window the walk will most likely enter in the
-// strip above is fetched into registers while the current strip is being walked.
+// ---- backtrack over the packed, skewed step codes ----------------------------------------------------------------
+// The path from (M-1, N-1) to (0, 0) is found strip by strip.  The DP left, for every cell of a strip's bottom row,
+// the column at which its best path came in from the strip above (Problem::entb), so the columns at which the path
+// crosses the strip boundaries follow from one dependent load per strip (hops); then every strip's segment is walked
+// independently -- one wave per strip, all strips at once -- first to count its points, then to write them straight
+// to their final, forward-ordered positions.
+//
+// A walk is a uniform (scalar) loop: the position lives in SGPRs, every lane keeps the code word of ITS row for the
+// current 16-step chunk in a register and the step code is one v_readlane away, so no step waits for memory.  A
+// window of kBtChunks chunks of the strip is staged in LDS (`win`: [2][kBtChunks][64] dwords) and the next window to
+// the left is fetched into registers while the current one is being walked.
 constexpr int kBtChunks = 8;
 
-__device__ __forceinline__ int backtrack(const uint32_t *codes, int M, int N, int32_t *rev, int cap, uint32_t *win) {
+// Walks from (i, j) while the position stays inside strip (i >> 6) and has not reached (0, 0).  Visited points
+// (the start included, the first point outside the strip excluded) are written to out[2 * (out_last - k)] for the
+// k-th visited point when `out` is not null.  Returns the number of visited points; (i, j) is left at the first
+// position outside the strip (or at (0, 0), which counts as visited).
+__device__ __forceinline__ int walk_strip(const uint32_t *codes, int N, int &i, int &j, int32_t *out, int out_last,
+                                          uint32_t *win) {
     const int lane = threadIdx.x & 63;
     const int nch = n_chunks(N);
-    int i = M - 1, j = N - 1, len = 1;
-    if (lane == 0 && cap > 0) {
-        rev[0] = i;
-        rev[1] = j;
-    }
-    int buf = 0;
-    // staged window: strip ws, chunks [wlo, wlo + kBtChunks)
-    int ws = -1, wlo = 0;
-    // prefetched (registers) window: strip ps, chunks [plo, plo + kBtChunks)
-    int ps = -1, plo = 0;
+    const int strip = i >> 6;
+    int n = 0, buf = 0, wlo = 0, plo = 0;
+    bool have_pf = false;
     uint32_t pf[kBtChunks];
 #pragma unroll
     for (int k = 0; k < kBtChunks; k++) pf[k] = 0;
-    auto fetch = [&](int strip, int lo) {  // chunk indices below 0 or beyond nch-1 are never walked
+    auto fetch = [&](int lo) {  // chunk indices below 0 or beyond nch-1 are never walked
 #pragma unroll
         for (int k = 0; k < kBtChunks; k++) {
             const int c = lo + k;
-            pf[k] = (strip >= 0 && c >= 0 && c < nch) ? codes[((size_t)strip * nch + c) * 64 + lane] : 0u;
+            pf[k] = (c >= 0 && c < nch) ? codes[((size_t)strip * nch + c) * 64 + lane] : 0u;
         }
-        ps = strip;
         plo = lo;
+        have_pf = true;
     };
     auto commit = [&]() {  // registers -> the other LDS buffer
         buf ^= 1;
 #pragma unroll
         for (int k = 0; k < kBtChunks; k++) win[(buf * kBtChunks + k) * 64 + lane] = pf[k];
-        ws = ps;
         wlo = plo;
-        ps = -1;
+        have_pf = false;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    while ((i > 0 || j > 0) && len < cap) {
-        const int strip = i >> 6;
+    bool inside = true;
+    while (inside) {
         const int c0 = (j + (i & 63)) >> 4;
-        if (!(ps == strip && c0 >= plo && c0 < plo + kBtChunks)) fetch(strip, c0 - kBtChunks + 1);
+        if (!(have_pf && c0 >= plo && c0 < plo + kBtChunks)) fetch(c0 - kBtChunks + 1);
         commit();
-        // the walk leaves this strip through its row 0 after at most (i & 63) + 1 upward moves; with a few moves to
-        // the left it enters the strip above at t = j' + 63 within the chunks fetched here
-        fetch(strip - 1, ((j + 63) >> 4) - kBtChunks + 1);
+        fetch(wlo - kBtChunks);  // the window further left, in case the walk gets there
         int ccur = c0;
         uint32_t cur = win[(buf * kBtChunks + (c0 - wlo)) * 64 + lane];
         uint32_t nxt = (c0 - 1 >= wlo) ? win[(buf * kBtChunks + (c0 - 1 - wlo)) * 64 + lane] : 0u;
-        while ((i > 0 || j > 0) && len < cap) {
-            const int l = i & 63, t = j + l, c = t >> 4;
-            if ((i >> 6) != strip || c < wlo) break;
-            if (c != ccur) {  // one chunk down (t shrinks by at most 2 per step)
-                cur = nxt;
-                ccur = c;
-                nxt = (c - 1 >= wlo) ? win[(buf * kBtChunks + (c - 1 - wlo)) * 64 + lane] : 0u;
+        for (;;) {
+            // the current position is inside the strip: visit it
+            if (out && lane == 0) *reinterpret_cast<int2 *>(out + 2 * (size_t)(out_last - n)) = make_int2(i, j);
+            n++;
+            if (i == 0 && j == 0) {
+                inside = false;
+                break;
             }
+            const int l = i & 63, t = j + l;
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, l);
             const int code = (w >> (2 * (t & 15))) & 3;
             i -= (code != kLeft) ? 1 : 0;  // kUp, kDiag
             j -= (code != kUp) ? 1 : 0;    // kLeft, kDiag
-            i = i < 0 ? 0 : i;             // a corrupted code cannot leave the matrix
-            j = j < 0 ? 0 : j;
-            if (lane == 0) *reinterpret_cast<int2 *>(rev + 2 * (size_t)len) = make_int2(i, j);
-            len++;
+            j = j < 0 ? 0 : j;             // a corrupted code cannot leave the matrix
+            if (i < 0) {
+                i = 0;
+                if (j == 0) {  // corrupted code at the origin row: stop instead of spinning
+                    inside = false;
+                    break;
+                }
+            }
+            if ((i >> 6) != strip) {
+                inside = false;
+                break;
+            }
+            const int c = (j + (i & 63)) >> 4;
+            if (c < wlo) break;  // restage further left
+            if (c != ccur) {     // one chunk down (t shrinks by at most 2 per step)
+                cur = nxt;
+                ccur = c;
+                nxt = (c - 1 >= wlo) ? win[(buf * kBtChunks + (c - 1 - wlo)) * 64 + lane] : 0u;
+            }
         }
     }
-    return len;
+    return n;
+}
+
+// One wave: cross[s] = column at which the path crosses the bottom row of strip s (s < S - 1), cross[S-1] = N - 1.
+__device__ __forceinline__ void path_hops(const uint32_t *codes, const int32_t *entb, int M, int N, int32_t *cross,
+                                          uint32_t *win) {
+    const int lane = threadIdx.x & 63;
+    const int S = n_strips(M);
+    int i = M - 1, j = N - 1;
+    if (lane == 0) cross[S - 1] = j;
+    if (S == 1) return;
+    walk_strip(codes, N, i, j, nullptr, 0, win);  // leaves the last strip at (64 (S-1) - 1, j)
+    for (int s = S - 2; s >= 0; s--) {
+        if (lane == 0) cross[s] = j;
+        if (s > 0) j = entb[(size_t)s * N + j];  // uniform load; one dependent round trip per strip
+        j = j < 0 ? 0 : (j >= N ? N - 1 : j);
+    }
+}
+
+// The segment of strip s: start point and walk.  pass 0: lens[s] = number of points.  pass 1: writes the points to
+// path[] (forward order) using the lens of all strips; *total (if not null, strip 0 only) receives the path length.
+__device__ __forceinline__ void path_segment(const uint32_t *codes, int M, int N, int s, const int32_t *cross,
+                                             int32_t *lens, int pass, int32_t *path, int32_t *total, uint32_t *win) {
+    const int lane = threadIdx.x & 63;
+    const int S = n_strips(M);
+    int i = (s == S - 1) ? M - 1 : 64 * s + 63, j = cross[s];
+    if (pass == 0) {
+        const int n = walk_strip(codes, N, i, j, nullptr, 0, win);
+        if (lane == 0) lens[s] = n;
+        return;
+    }
+    int off = 0, all = 0;  // points in the strips above mine come first
+    for (int q = lane; q < S; q += 64) {
+        const int v = lens[q];
+        all += v;
+        off += (q < s) ? v : 0;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        off += __shfl_xor(off, d);
+        all += __shfl_xor(all, d);
+    }
+    const int n = lens[s];
+    walk_strip(codes, N, i, j, path, off + n - 1, win);
+    if (total && s == 0 && lane == 0) *total = all;
 }
 
 }  // namespace sdp

@@ -15,9 +15,10 @@
 //
 // Windows of more than 512 frames (BASELINE configs[4]: W = 10 000) are a different regime -- one window is
 // 1e8 cells -- and run as a strip DP (sdp.h) spread over many workgroups: per window one launch of
-// wtw_big_dp_kernel (a pipeline of row groups down the W x W matrix, step codes packed 2 bits per cell) and one
-// of wtw_big_ctl_kernel (backtrack over the packed codes, hand-over, then the column bookkeeping of
-// wtw.py:92-100 up to the next window).  The host enqueues as many (dp, ctl) rounds as the pushed columns can
+// wtw_big_dp_kernel (a pipeline of row groups down the W x W matrix, step codes packed 2 bits per cell), the
+// backtrack kernels (wtw_big_hops_kernel, wtw_big_segment_kernel: every strip's path segment by its own wave) and
+// wtw_big_ctl_kernel (hand-over, then the column bookkeeping of
+// wtw.py:92-100 up to the next window).  The host enqueues as many such rounds as the pushed columns can
 // possibly complete windows; rounds with nothing pending return at once.  Everything stays asynchronous.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -49,6 +50,8 @@ struct WtwArgs {
     int32_t *ctl;              // [B][8]: pending, live_ptr, ref_ptr, n, m of the window being computed
     uint32_t *codes;           // [B][codes_words(W, W)] packed step codes
     unsigned long long *bnd;   // [B][n_strips(W)][W] rows handed between row groups
+    int32_t *entb;             // [B][n_strips(W)][W] entry columns of the strips' bottom rows (sdp.h)
+    int32_t *cross, *lens;     // [B][n_strips(W)] strip-boundary crossings / segment lengths of the window's path
     int32_t *err;
     int n_rg;
     int M, N, W, hopf, path_cap;
@@ -272,18 +275,40 @@ __global__ void __launch_bounds__(512) wtw_big_dp_kernel(WtwArgs g) {
     pb.ldD = g.W;
     pb.codes = g.codes + (size_t)b * sdp::codes_words(g.W, g.W);
     pb.bnd = g.bnd + (size_t)b * sdp::n_strips(g.W) * g.W;
+    pb.entb = g.entb + (size_t)b * sdp::n_strips(g.W) * g.W;
     pb.err = g.err;
     const int NW = blockDim.x >> 6;
     for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x) sdp::run_rowgroup<sdp::WtwPolicy, STAGE>(pb, rg, g.n_rg, NW, wtw_smem);
 }
 
-// One workgroup per stream.  If a window is pending (its step codes were just written by wtw_big_dp_kernel):
-// find_path (wtw.py:219-240) + hand-over (wtw.py:107-128).  Then the column bookkeeping of wtw.py:92-100 in closed
+// find_path (wtw.py:219-240) for the pending window of each stream, over the packed step codes (sdp.h): the
+// strip-boundary crossings, then every strip's segment by its own wave -- count, then write -- into ws_sub,
+// forward-ordered; ctl[5] receives the sub-path's length.
+__global__ void __launch_bounds__(64) wtw_big_hops_kernel(WtwArgs g) {
+    __shared__ uint32_t win[2 * sdp::kBtChunks * 64];
+    const int b = blockIdx.x, S = sdp::n_strips(g.W);
+    const int32_t *ctl = g.ctl + (size_t)b * 8;
+    if (ctl[0] == 0) return;
+    sdp::path_hops(g.codes + (size_t)b * sdp::codes_words(g.W, g.W), g.entb + (size_t)b * S * g.W, ctl[3], ctl[4],
+                   g.cross + (size_t)b * S, win);
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(64) wtw_big_segment_kernel(WtwArgs g) {
+    __shared__ uint32_t win[2 * sdp::kBtChunks * 64];
+    const int b = blockIdx.y, s = blockIdx.x, S = sdp::n_strips(g.W);
+    int32_t *ctl = g.ctl + (size_t)b * 8;
+    if (ctl[0] == 0 || s >= sdp::n_strips(ctl[3])) return;
+    sdp::path_segment(g.codes + (size_t)b * sdp::codes_words(g.W, g.W), ctl[3], ctl[4], s, g.cross + (size_t)b * S,
+                      g.lens + (size_t)b * S, PASS, g.ws_sub + (size_t)b * 4 * g.W, ctl + 5, win);
+}
+
+// One workgroup per stream.  If a window is pending (its sub-path was just written by the kernels above): the
+// hand-over (wtw.py:107-128).  Then the column bookkeeping of wtw.py:92-100 in closed
 // form up to the next event: between two windows the stop test (wtw.py:96) sees constant pointers, and a window
 // fires exactly when chroma_ptr reaches live_ptr + W.
 __global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) {
-    __shared__ uint32_t win[2 * sdp::kBtChunks * 64];
-    __shared__ int s_len, s_cnt;
+    __shared__ int s_cnt;
     const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int W = g.W;
     int32_t *st = g.state + (size_t)b * 8;
@@ -295,31 +320,26 @@ __global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) {
     const int n = ctl[3], m = ctl[4];
     int live_ptr = st[1], ref_ptr = st[2], n_path = st[4];
     if (tid == 0) s_cnt = 0;
+    __syncthreads();
     if (pending) {
-        if (tid < 64) {
-            const int len = sdp::backtrack(g.codes + (size_t)b * sdp::codes_words(W, W), n, m, sub, 2 * W, win);
-            if (tid == 0) s_len = len;
-        }
-        __syncthreads();
-        // sub[] holds the path reversed; l is non-decreasing along the forward path, so the points handed over
+        // sub[] holds the path from (0, 0) to (n-1, m-1); l is non-decreasing along it, so the points handed over
         // (l <= dtw_hop / hop, wtw.py:113) are a prefix of it
-        const int len = s_len;
+        int len = ctl[5];
+        len = len < 1 ? 1 : (len > 2 * W ? 2 * W : len);
         int local = 0;
         for (int q = tid; q < len; q += NT) local += (sub[2 * q] <= g.hopf) ? 1 : 0;
         if (local) atomicAdd(&s_cnt, local);
         __syncthreads();
         const int cnt = s_cnt;
         for (int f = tid; f < cnt; f += NT) {
-            const int q = len - 1 - f;
             if (n_path + f < g.path_cap) {
-                path[2 * (size_t)(n_path + f)] = sub[2 * q] + lp;
-                path[2 * (size_t)(n_path + f) + 1] = sub[2 * q + 1] + rp;
+                path[2 * (size_t)(n_path + f)] = sub[2 * f] + lp;
+                path[2 * (size_t)(n_path + f) + 1] = sub[2 * f + 1] + rp;
             }
         }
-        if (cnt < len) {  // "change": the path went past the hop (wtw.py:118-124)
-            const int q = len - cnt;  // last appended point = forward index cnt - 1
-            live_ptr = lp + sub[2 * q];
-            ref_ptr = rp + sub[2 * q + 1];
+        if (cnt < len && cnt >= 1) {  // "change": the path went past the hop (wtw.py:118-124)
+            live_ptr = lp + sub[2 * (cnt - 1)];  // the last appended point
+            ref_ptr = rp + sub[2 * (cnt - 1) + 1];
         } else {
             live_ptr = lp + g.hopf;
             ref_ptr = rp + g.hopf;
@@ -419,7 +439,7 @@ struct rts_wtw {
     int32_t *appended, *state, *path;
     int8_t *bwork;
     double *dlast;
-    int32_t *ws_sub, *ctl, *err;
+    int32_t *ws_sub, *ctl, *err, *entb, *cross, *lens;
     uint32_t *codes;
     unsigned long long *bnd;
     int big_waves, n_rg, big_grid;
@@ -479,6 +499,9 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         (big && (e = hipMalloc((void **)&h->err, 16)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->codes, sizeof(uint32_t) * sdp::codes_words(W, W) * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->bnd, sizeof(unsigned long long) * (size_t)sdp::n_strips(W) * W * B)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->entb, sizeof(int32_t) * (size_t)sdp::n_strips(W) * W * B)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->cross, sizeof(int32_t) * (size_t)sdp::n_strips(W) * B)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->lens, sizeof(int32_t) * (size_t)sdp::n_strips(W) * B)) != hipSuccess) ||
         (keep_last_d && (e = hipMalloc((void **)&h->dlast, sizeof(double) * (size_t)B * W * W)) != hipSuccess) ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess ||
@@ -517,6 +540,9 @@ int rts_wtw_destroy(rts_wtw *h) {
     if (h->err) (void)hipFree(h->err);
     if (h->codes) (void)hipFree(h->codes);
     if (h->bnd) (void)hipFree(h->bnd);
+    if (h->entb) (void)hipFree(h->entb);
+    if (h->cross) (void)hipFree(h->cross);
+    if (h->lens) (void)hipFree(h->lens);
     free(h);
     return RTS_OK;
 }
@@ -562,6 +588,9 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.ctl = h->ctl;
     g.codes = h->codes;
     g.bnd = h->bnd;
+    g.entb = h->entb;
+    g.cross = h->cross;
+    g.lens = h->lens;
     g.err = h->err;
     g.n_rg = h->n_rg;
     g.M = h->M;
@@ -579,6 +608,9 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
                 hipLaunchKernelGGL((wtw_big_dp_kernel<true>), dim3(h->big_grid, h->B), dim3(64 * h->big_waves), h->smem, s, g);
             else
                 hipLaunchKernelGGL((wtw_big_dp_kernel<false>), dim3(h->big_grid, h->B), dim3(64 * h->big_waves), h->smem, s, g);
+            hipLaunchKernelGGL(wtw_big_hops_kernel, dim3(h->B), dim3(64), 0, s, g);
+            hipLaunchKernelGGL((wtw_big_segment_kernel<0>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
+            hipLaunchKernelGGL((wtw_big_segment_kernel<1>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
             hipLaunchKernelGGL(wtw_big_ctl_kernel, dim3(h->B), dim3(1024), 0, s, g);
         }
     } else if (h->W > kWtwLdsB) {
