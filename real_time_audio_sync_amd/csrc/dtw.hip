@@ -36,8 +36,9 @@ struct DtwArgs {
     unsigned long long *bnd;   // [B][n_strips][N]
     int32_t *entb;             // [B][n_strips][N]
     int32_t *cross, *lens;     // [B][n_strips]
+    double *yrec;              // [B][N][14] prepared column records
     int32_t *err;
-    int n_rg;
+    int n_rg, n_strips_wg;
 };
 
 // One thread per column j and kCostRows consecutive rows: b_j stays in registers, the a rows are wave-uniform
@@ -64,17 +65,27 @@ __global__ void __launch_bounds__(256) dtw_cost_kernel(DtwArgs g) {
     }
 }
 
-__global__ void __launch_bounds__(512) dtw_sdp_kernel(DtwArgs g) {
+
+__global__ void __launch_bounds__(256) dtw_prep_kernel(DtwArgs g) {
+    const int pair = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= g.N) return;
+    const void *b = g.b_f64 ? (const void *)(reinterpret_cast<const double *>(g.b) + (long long)pair * g.b_stride * kDtwF)
+                            : (const void *)(reinterpret_cast<const float *>(g.b) + (long long)pair * g.b_stride * kDtwF);
+    sdp::prep_column<sdp::DtwPolicy>(b, g.b_f64, j, g.yrec + (size_t)pair * g.N * sdp::kYRec);
+}
+
+// H helper waves per strip.  <2>: two strips per workgroup (6 waves); <3>: one strip per workgroup (4 waves, the DP wave
+// has a SIMD to itself) -- see sdp::pick_config.
+template <int H>
+__global__ void __launch_bounds__(H == 2 ? 384 : 256) dtw_sdp_kernel(DtwArgs g) {
     extern __shared__ __align__(16) unsigned char dtw_smem[];
     const int pair = blockIdx.y;
-    const int NW = blockDim.x >> 6;
     sdp::Problem pb;
     pb.x = g.a_f64 ? (const void *)(reinterpret_cast<const double *>(g.a) + (long long)pair * g.a_stride * kDtwF)
                    : (const void *)(reinterpret_cast<const float *>(g.a) + (long long)pair * g.a_stride * kDtwF);
-    pb.y = g.b_f64 ? (const void *)(reinterpret_cast<const double *>(g.b) + (long long)pair * g.b_stride * kDtwF)
-                   : (const void *)(reinterpret_cast<const float *>(g.b) + (long long)pair * g.b_stride * kDtwF);
     pb.x_f64 = g.a_f64;
-    pb.y_f64 = g.b_f64;
+    pb.yrec = g.yrec + (size_t)pair * g.N * sdp::kYRec;
     pb.M = g.M;
     pb.N = g.N;
     pb.D = g.acc + (size_t)pair * g.M * g.N;
@@ -83,7 +94,8 @@ __global__ void __launch_bounds__(512) dtw_sdp_kernel(DtwArgs g) {
     pb.bnd = g.bnd + (size_t)pair * sdp::n_strips(g.M) * g.N;
     pb.entb = g.entb + (size_t)pair * sdp::n_strips(g.M) * g.N;
     pb.err = g.err;
-    for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x) sdp::run_rowgroup<sdp::DtwPolicy, true>(pb, rg, g.n_rg, NW, dtw_smem);
+    for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x)
+        sdp::run_rowgroup<sdp::DtwPolicy, true, H>(pb, rg, g.n_rg, g.n_strips_wg, dtw_smem);
 }
 
 __global__ void __launch_bounds__(64) dtw_hops_kernel(DtwArgs g) {
@@ -115,14 +127,6 @@ __global__ void __launch_bounds__(256) dtw_back_decode_kernel(DtwArgs g) {
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static int dtw_waves() {  // tuning knob (results do not depend on it): waves per workgroup for multi-row-group pairs
-    const char *e = getenv("RTS_SDP_WAVES");
-    int v = e ? atoi(e) : 4;
-    if (v < 1) v = 1;
-    if (v > sdp::kMaxWaves) v = sdp::kMaxWaves;
-    return v;
-}
-
 }  // namespace rts
 
 extern "C" {
@@ -133,7 +137,8 @@ int rts_dtw_workspace_bytes(int M, int N, int B, size_t *bytes) {
     if (M < 1 || N < 1 || B < 1) return set_error(RTS_ERR_INVALID, "M, N, B must be >= 1");
     const size_t strips = (size_t)B * sdp::n_strips(M);
     *bytes = 256 + align256(sizeof(unsigned long long) * strips * N) + align256(sizeof(int32_t) * strips * N) +
-             2 * align256(sizeof(int32_t) * strips) + align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N));
+             2 * align256(sizeof(int32_t) * strips) + align256(sizeof(double) * (size_t)B * N * sdp::kYRec) +
+             align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N));
     return RTS_OK;
 }
 
@@ -157,11 +162,9 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
     if (((uintptr_t)ws_dev & 15) != 0) return set_error(RTS_ERR_INVALID, "workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int strips = sdp::n_strips(M);
-    const int NW = strips <= sdp::kMaxWaves ? strips : dtw_waves();
-    const int n_rg = (strips + NW - 1) / NW;
-    int G = 256 / B;  // every workgroup of a multi-row-group pipeline must be resident: at most one per CU
-    if (G < 1) G = 1;
-    if (G > n_rg) G = n_rg;
+    int NS, H, G;
+    sdp::pick_config(strips, B, NS, H, G);
+    const int n_rg = (strips + NS - 1) / NS;
     unsigned char *ws = reinterpret_cast<unsigned char *>(ws_dev);
     DtwArgs g;
     g.a = a_dev;
@@ -188,9 +191,12 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
         p += align256(sizeof(int32_t) * (size_t)B * strips);
         g.lens = reinterpret_cast<int32_t *>(p);
         p += align256(sizeof(int32_t) * (size_t)B * strips);
+        g.yrec = reinterpret_cast<double *>(p);
+        p += align256(sizeof(double) * (size_t)B * N * sdp::kYRec);
         g.codes = reinterpret_cast<uint32_t *>(p);
     }
     g.n_rg = n_rg;
+    g.n_strips_wg = NS;
     RTS_HIP(hipMemsetAsync(g.err, 0, 16, s));
     if (n_rg > 1) RTS_HIP(hipMemsetD32Async((hipDeviceptr_t)g.bnd, (int)sdp::kSentinel32, (size_t)2 * B * strips * N, s));
     {
@@ -205,10 +211,17 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
             hipLaunchKernelGGL((dtw_cost_kernel<false, false>), grid, dim3(256), 0, s, g);
     }
     RTS_HIP(hipGetLastError());
-    const size_t smem = sdp::lds_bytes(NW, true);
-    RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(dtw_sdp_kernel, dim3(G, B), dim3(64 * NW), smem, s, g);
+    hipLaunchKernelGGL(dtw_prep_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, g);
+    const size_t smem = sdp::lds_bytes(NS);
+    if (H == 2) {
+        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((dtw_sdp_kernel<2>), dim3(G, B), dim3(64 * NS * 3), smem, s, g);
+    } else {
+        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((dtw_sdp_kernel<3>), dim3(G, B), dim3(64 * NS * 4), smem, s, g);
+    }
     RTS_HIP(hipGetLastError());
     hipLaunchKernelGGL(dtw_hops_kernel, dim3(B), dim3(64), 0, s, g);
     hipLaunchKernelGGL((dtw_segment_kernel<0>), dim3(strips, B), dim3(64), 0, s, g);

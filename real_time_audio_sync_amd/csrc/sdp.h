@@ -8,13 +8,21 @@
 // a step needs no barrier and no LDS round trip for the recurrence.  Each cell performs exactly the
 // reference's float64 operations in the reference's order, hence bit-identical results.
 //
-// A workgroup of NW waves owns a ROW GROUP of NW consecutive strips; wave w runs kLag chunks (80
-// steps) behind wave w-1 and takes the bottom row of the strip above from a small LDS ring.  All waves
-// of a workgroup advance in lockstep, one LDS-only barrier per chunk of 16 steps, which also publishes
-// the column features that one wave stages into an LDS ring for everyone (14-double records: a 112-byte
-// stride is conflict-free for ds_read_b128).  Consecutive row groups run on different workgroups of the
-// same launch, pipelined the same way through HBM: the last wave publishes its strip's bottom row as
-// 8-byte write-through (sc1) stores, the next row group's first wave polls those words with sc1 loads.
+// Roles.  A strip is served by 1 + H waves.  Its DP wave does nothing but the recurrence: per step one
+// ds_read_b64 of the cell cost, two DPP moves, the compares/selects, and the bookkeeping of the outputs.  Its H
+// HELPER waves produce the costs one chunk (16 columns) ahead: lane = row again, but they sweep whole columns,
+// so the column's feature record is wave-uniform -- helper 0 stages the next chunk's 16 records (1.8 KB) in LDS
+// while the current ones are consumed, and every lane reads the same address (a broadcast, seven ds_read_b128
+// per column instead of per cell) -- and each cost goes to the slot (step = column + row, lane = row) of a
+// 96-step LDS cost ring that the DP wave reads as consecutive 512-byte rows.  Helper 0 also moves the
+// accumulated costs of the previous chunk from the DP wave's LDS tile to HBM.
+//
+// A workgroup owns a ROW GROUP of NS <= 2 consecutive strips; strip s+1 runs kLag chunks (80 steps) behind
+// strip s and reads the bottom row of the strip above straight from that strip's output tiles (three tiles
+// per strip, so a tile outlives its two readers).  All waves of a workgroup advance in lockstep, one LDS-only
+// barrier per chunk of 16 steps.  Consecutive row groups run on different workgroups of the same launch,
+// pipelined the same way through HBM: the bottom row of a row group's last strip is published as
+// 8-byte write-through (sc1) stores, the next row group's first DP wave polls those words with sc1 loads.
 // The data is its own flag: the boundary buffer is pre-filled with a signalling-NaN bit pattern that no
 // float64 add/subtract can produce (arithmetic results are always quiet), so a word that differs from
 // it is the value (single naturally aligned 8-byte store: untorn; no fences, no separate flag).
@@ -22,11 +30,12 @@
 // Outputs.  Back-pointers: 2 bits per cell, 16 steps of a lane packed into one dword, stored in skewed
 // order [strip][chunk][lane] (one coalesced 256-byte store per wave and chunk) -- the backtrack below
 // decodes that layout.  The accumulated-cost matrix (dtw.py's acc_cost, wtw.py's D), when wanted, is
-// transposed through a per-wave LDS tile so that HBM sees 128-byte row segments instead of 64 scattered
+// transposed through the strip's LDS tiles so that HBM sees 128-byte row segments instead of 64 scattered
 // 8-byte stores per step.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -36,10 +45,11 @@ namespace sdp {
 constexpr int kF = 12;
 constexpr int kChunk = 16;     // steps between two workgroup barriers
 constexpr int kLag = 5;        // chunks wave w+1 runs behind wave w: lane 63 finishes column 16m+15 at step 16m+78
-constexpr int kYRec = 14;      // doubles per column record in the LDS ring: 12 features, norm, pad
-constexpr int kBRing = 128;    // boundary ring entries between consecutive waves
-constexpr int kStageLd = 65;   // leading dimension of the [16][64] output staging tile
-constexpr int kMaxWaves = 8;
+constexpr int kYRec = 14;      // doubles per prepared column record: 12 features, norm, pad (112 bytes)
+constexpr int kRing = 96;      // steps of the LDS cost ring: a helper runs one chunk ahead and a column spans 64 steps
+constexpr int kStageLd = 65;   // leading dimension of the [16][64] output tiles
+constexpr int kTiles = 3;      // output tiles per strip: written in chunk m, read in chunks m+1 and m+2
+constexpr int kMaxStrips = 2;  // strips per workgroup (LDS: 77 696 bytes per strip)
 constexpr unsigned long long kSentinel = 0x7FF4DEAD7FF4DEADull;  // signalling NaN: never an arithmetic result
 constexpr uint32_t kSentinel32 = 0x7FF4DEADu;                    // the same as a 32-bit fill pattern
 constexpr int kSpinLimit = 1 << 22;
@@ -51,17 +61,32 @@ constexpr int kDiag = 2;  // from (i-1, j-1)
 
 __host__ __device__ inline int n_strips(int M) { return (M + 63) / 64; }
 __host__ __device__ inline int n_chunks(int N) { return (N + 63 + kChunk - 1) / kChunk; }  // per strip
-__host__ __device__ inline int yring_slots(int NW) { return kLag * kChunk * (NW - 1) + 112; }
-__host__ __device__ inline size_t lds_bytes(int NW, bool stage) {
-    return sizeof(double) * ((size_t)(yring_slots(NW) + kChunk) * kYRec + (size_t)NW * kBRing +
-                             (stage ? (size_t)NW * kChunk * kStageLd : 0));
+__host__ __device__ inline size_t lds_bytes(int NS) {
+    return sizeof(double) * (size_t)NS * ((size_t)kRing * 64 + (size_t)kTiles * kChunk * kStageLd + 2 * kChunk * kYRec + 64 + 2 * kChunk);
+}
+// Strips per workgroup / helper waves per strip / workgroups of one problem's pipeline.  One strip per workgroup
+// (3 helpers; the DP wave, which sets the pace, has a SIMD to itself; 77 KB of LDS, so two workgroups share a CU) when
+// every strip of every problem can have a resident workgroup of its own; otherwise two strips per workgroup (2 helpers
+// each), which halves the number of passes a workgroup makes over the columns.  A problem's row groups wait for one
+// another inside the launch, so all of them must be resident: `grid` workgroups per problem at most.
+// RTS_SDP_CONFIG=1|2 forces the strips per workgroup (tuning; results do not depend on it).
+inline void pick_config(int strips, int B, int &NS, int &H, int &grid) {
+    NS = ((long long)strips * B <= 512) ? 1 : 2;
+    if (const char *e = getenv("RTS_SDP_CONFIG")) NS = (atoi(e) == 1) ? 1 : 2;
+    if (NS > strips) NS = strips;
+    H = (NS == 1) ? 3 : 2;
+    const int n_rg = (strips + NS - 1) / NS;
+    const int resident = (NS == 1) ? 512 : 256;  // 256 CUs x workgroups per CU
+    grid = resident / B;
+    if (grid < 1) grid = 1;
+    if (grid > n_rg) grid = n_rg;
 }
 __host__ __device__ inline size_t codes_words(int M, int N) { return (size_t)n_strips(M) * n_chunks(N) * 64; }
 
 struct Problem {
-    const void *x;  // row features [M][12]
-    const void *y;  // column features [N][12]
-    int x_f64, y_f64;
+    const void *x;        // row features [M][12]
+    int x_f64;
+    const double *yrec;   // prepared column records [N][kYRec] (prep_column)
     int M, N;
     double *D;             // optional row-major output, leading dimension ldD
     long long ldD;
@@ -120,12 +145,20 @@ __device__ __forceinline__ void store_sc1(unsigned long long *p, unsigned long l
     __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dwordx2 sc1
 }
 
+// v_min_f64 as is (fmin() would wrap it in canonicalising v_max pairs).  IEEE minNum: a NaN operand is ignored.
+__device__ __forceinline__ double vmin(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---- policies: the per-cell arithmetic of the two reference recurrences ---------------------------------------
 
 // dtw.py:11 cost = 1 - seq_a.T . seq_b (dgemm k-order: one fma chain), dtw.py:32-40 options (left, up, diag + 2c),
 // np.argmin = first minimum.
 struct DtwPolicy {
     static constexpr bool kNorm = false;
+    static constexpr int kHelper0Cols = 0;  // cost columns per chunk on the helper that also runs the entry-column pass
     static __device__ __forceinline__ double norm(const double (&)[kF]) { return 0.0; }
     static __device__ __forceinline__ double cost(const double (&x)[kF], double, const double (&y)[kF], double) {
         double s = 0.0;
@@ -135,17 +168,14 @@ struct DtwPolicy {
     }
     static __device__ __forceinline__ void cell(bool first_row, bool first_col, double up, double left, double diag,
                                                 double c, double &dv, int &code) {
+        // value and step code separately: the value is what the next step waits for (two v_min_f64 instead of two
+        // compare-and-select pairs); the code -- np.argmin's first minimum -- comes from compares off that chain.
+        // Same results for finite inputs (chroma columns are finite; NaN inputs are outside dtw.py's domain).
         const double o0 = left + c, o1 = up + c, o2 = diag + 2 * c;
-        double best = o0;
-        int s = kLeft;
-        if (o1 < best) {
-            best = o1;
-            s = kUp;
-        }
-        if (o2 < best) {
-            best = o2;
-            s = kDiag;
-        }
+        const double m01 = vmin(o0, o1);
+        double best = vmin(m01, o2);
+        int s = (o1 < o0) ? kUp : kLeft;
+        s = (o2 < m01) ? kDiag : s;
         if (first_col) {  // dtw.py:23-25
             best = o1;
             s = kUp;
@@ -167,6 +197,7 @@ struct DtwPolicy {
 // are fma chains), wtw.py:201-215 candidates (i-1,j), (i,j-1), (i-1,j-1) with strict '<' in that order.
 struct WtwPolicy {
     static constexpr bool kNorm = true;
+    static constexpr int kHelper0Cols = 2;  // a normalised-cosine cost is ~3x the work of a plain dot product
     static __device__ __forceinline__ double norm(const double (&v)[kF]) {
         double s = 0.0;
 #pragma unroll
@@ -188,16 +219,14 @@ struct WtwPolicy {
     }
     static __device__ __forceinline__ void cell(bool first_row, bool first_col, double up, double left, double diag,
                                                 double c, double &dv, int &code) {
-        double mc = up;
-        int s = kUp;
-        if (left < mc) {
-            mc = left;
-            s = kLeft;
-        }
-        if (diag < mc) {
-            mc = diag;
-            s = kDiag;
-        }
+        // wtw.py:201-215 replaces min_cost only by a strictly smaller candidate, so a NaN candidate (silent frame) is
+        // ignored -- v_min_f64 does exactly that -- while a NaN in min_cost's initial value, (i-1, j), stays
+        double mc = vmin(vmin(up, left), diag);
+        const bool up_nan = (up != up);
+        mc = up_nan ? up : mc;
+        int s = (left < up) ? kLeft : kUp;
+        s = (diag < vmin(up, left)) ? kDiag : s;
+        s = up_nan ? kUp : s;
         if (first_col) {  // wtw.py:187-191
             mc = up;
             s = kUp;
@@ -229,120 +258,285 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-// ---- one row group (NW strips) of one problem, executed by the whole workgroup ----------------------------------
-template <class P, bool STAGE>
-__device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg, int NW, unsigned char *smem) {
+// ---- column records: float64 features (+ norm where the cost needs it), 112 bytes, one thread per column ----------
+template <class P>
+__device__ __forceinline__ void prep_column(const void *y, int y_f64, long long col, double *yrec) {
+    double v[kF];
+    load_frame(y, y_f64, col, v);
+    double2 *rec = reinterpret_cast<double2 *>(yrec + (size_t)col * kYRec);
+#pragma unroll
+    for (int k = 0; k < kF / 2; k++) rec[k] = make_double2(v[2 * k], v[2 * k + 1]);
+    rec[kF / 2] = make_double2(P::kNorm ? P::norm(v) : 0.0, 0.0);
+}
+
+// Division of labour among the H helper waves of a strip.  Helper 0 stages the column records and runs the (serial)
+// entry-column recurrence, so it takes few or no cost columns and none of the output traffic.
+__host__ __device__ constexpr bool helper_takes_column(int H, int hidx, int kk, int h0cols) {  // kk: column in the chunk
+    if (H == 3) return kk < h0cols ? hidx == 0 : (hidx != 0 && ((kk - h0cols) & 1) == (hidx - 1));
+    return hidx == 0 ? (kk % 8) < 3 : (kk % 8) >= 3;  // H == 2: 6 + 10
+}
+__host__ __device__ constexpr bool helper_takes_rows(int H, int hidx, int it) {  // it: group of 8 tile rows
+    if (H == 3) return hidx != 0 && (it & 1) == (hidx - 1);
+    return hidx == 1;
+}
+
+// ---- one row group (NS strips) of one problem, executed by the whole workgroup ----------------------------------
+// Waves: block 0 = helper 0 of strips 0..NS-1, block 1 = the DP waves, blocks 2.. = further helpers (with NS = 2 and
+// H = 2 the two DP waves are waves 2 and 3 and have a SIMD to themselves).
+template <class P, bool STAGE, int H>
+__device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg, int NS, unsigned char *smem) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
+    const int blk = wave / NS, sidx = wave - blk * NS;  // my strip within the row group
+    const bool is_dp = (blk == 1);
+    const int hidx = (blk == 0) ? 0 : blk - 1;  // helper index (helpers only)
     const int M = pb.M, N = pb.N;
-    const int YR = yring_slots(NW);
-    double *yring = reinterpret_cast<double *>(smem);  // [YR + 16] records; the last 16 mirror the first 16
-    double *bring = yring + (size_t)(YR + kChunk) * kYRec;
-    double *stage = bring + (size_t)NW * kBRing;
-    double *bring_w = bring + wave * kBRing;                              // my strip's bottom row
-    const double *bring_up = bring + (wave > 0 ? wave - 1 : 0) * kBRing;  // the strip above
-    double *stage_w = stage + (STAGE ? wave * kChunk * kStageLd : 0);
+    double *cring = reinterpret_cast<double *>(smem) + (size_t)sidx * kRing * 64;         // [kRing][64] cell costs
+    double *tiles = reinterpret_cast<double *>(smem) + (size_t)NS * kRing * 64;           // [NS][kTiles][16][65]
+    double *tile_mine = tiles + (size_t)sidx * kTiles * kChunk * kStageLd;
+    const double *tile_up = tiles + (size_t)(sidx > 0 ? sidx - 1 : 0) * kTiles * kChunk * kStageLd;
+    double *yst = tiles + (size_t)NS * kTiles * kChunk * kStageLd + (size_t)sidx * 2 * kChunk * kYRec;  // [2][16][kYRec]
+    // the DP wave's packed step codes of its last two chunks, for the helper that derives the entry columns from them
+    uint32_t *codes_l = reinterpret_cast<uint32_t *>(tiles + (size_t)NS * kTiles * kChunk * kStageLd +
+                                                     (size_t)NS * 2 * kChunk * kYRec) + (size_t)sidx * 128;  // [2][64]
+    // row-group boundary: the bottom row of the row group above, fetched from HBM by helper 0 one chunk ahead
+    double *upin = tiles + (size_t)NS * kTiles * kChunk * kStageLd + (size_t)NS * 2 * kChunk * kYRec + (size_t)NS * 64;  // [2][16]
 
-    const int strip = rg * NW + wave;
+    const int strip = rg * NS + sidx;
     const bool strip_ok = strip * 64 < M;
     const int i = strip * 64 + lane;
     const int nch = n_chunks(N);
-    const int total = nch + kLag * (NW - 1);
-    const bool from_hbm = (wave == 0 && rg > 0);
-    const bool to_hbm = (wave == NW - 1 && rg + 1 < n_rg);
+    const int ncc = (N + kChunk - 1) / kChunk;  // chunks of columns
+    const int total = nch + kLag * (NS - 1) + 2;  // + the helpers' head start and the last tile's way out
+    const bool from_hbm = (sidx == 0 && rg > 0);
+    const bool to_hbm = (sidx == NS - 1 && rg + 1 < n_rg);
     const unsigned long long *bnd_in = pb.bnd + (size_t)(rg > 0 ? rg - 1 : 0) * N;
     unsigned long long *bnd_out = pb.bnd + (size_t)rg * N;
 
-    double x[kF];
-    {
-        const int ic = i < M ? i : M - 1;
-        load_frame(pb.x, pb.x_f64, ic, x);
-    }
-    const double nx = P::norm(x);
-
-    auto stage_columns = [&](int first_col) {  // 16 lanes: one column record each
-        const int col = first_col + lane;
-        if (lane < kChunk && col < N) {
-            double y[kF];
-            load_frame(pb.y, pb.y_f64, col, y);
-            const double ny = P::kNorm ? P::norm(y) : 0.0;
-            const int slot = col % YR;
-            double2 *rec = reinterpret_cast<double2 *>(yring + (size_t)slot * kYRec);
-#pragma unroll
-            for (int k = 0; k < kF / 2; k++) rec[k] = make_double2(y[2 * k], y[2 * k + 1]);
-            if (P::kNorm) rec[kF / 2] = make_double2(ny, 0.0);
-            if (slot < kChunk) {
-                rec += (size_t)YR * kYRec / 2;
-#pragma unroll
-                for (int k = 0; k < kF / 2; k++) rec[k] = make_double2(y[2 * k], y[2 * k + 1]);
-                if (P::kNorm) rec[kF / 2] = make_double2(ny, 0.0);
-            }
+    if (!is_dp) {
+        // ================================ helper wave =========================================================
+        double x[kF];
+        {
+            const int ic = i < M ? i : M - 1;
+            load_frame(pb.x, pb.x_f64, ic, x);
         }
-    };
-    if (wave == 0) stage_columns(0);
-    lds_barrier();
+        const double nx = P::norm(x);
+        int ent = 0, ent_upprev = 0;  // helper 0: entry columns (see Problem::entb) of my row's last cell / its upper-left
+        bool dead = false;            // helper 0: a poll of the row-group boundary ran into its bound
+#ifdef RTS_SDP_STAMPS
+        long long sh_cost = 0, sh_flush = 0, sh_bar = 0;
+#endif
+        // the records of column chunk `cc` as 112 16-byte pieces: lane l holds pieces l and l + 64 (columns past the
+        // last one repeat it: their costs land in ring slots no valid cell reads)
+        double2 pc0 = make_double2(0.0, 0.0), pc1 = pc0;
+        auto fetch_records = [&](int cc) {
+            const double2 *src = reinterpret_cast<const double2 *>(pb.yrec);
+            const int p0 = lane, p1 = lane + 64;
+            int c_a = kChunk * cc + p0 / 7, c_b = kChunk * cc + p1 / 7;
+            c_a = c_a < N ? c_a : N - 1;
+            c_b = c_b < N ? c_b : N - 1;
+            pc0 = src[(size_t)c_a * 7 + p0 % 7];
+            if (p1 < kChunk * 7) pc1 = src[(size_t)c_b * 7 + p1 % 7];
+        };
+        auto commit_records = [&](int cc) {
+            double2 *dst = reinterpret_cast<double2 *>(yst + (size_t)(cc & 1) * kChunk * kYRec);
+            dst[lane] = pc0;
+            if (lane + 64 < kChunk * 7) dst[lane + 64] = pc1;
+        };
+        // the helper's role is fixed for the launch: one specialised loop per helper index, no per-column tests
+        auto helper_main = [&](auto hic) {
+        constexpr int HIDX = decltype(hic)::value;
+        for (int k = -1; k < total; k++) {
+            if (strip_ok) {
+                const int mh = k - kLag * sidx;
+                // ---- helper 0: fetch the records of the next column chunk now, park them in LDS at the end of the chunk
+                const bool pre = (HIDX == 0) && (mh + 1 >= 0) && (mh + 1 < ncc);
+                if (pre) fetch_records(mh + 1);
+                // ---- helper 0 of a row group's first strip: the bottom row of the row group above, columns
+                //      [16 mh, 16 mh + 16), which the DP wave enters in its next chunk.  Issued now, examined at the end.
+                const bool poll = (HIDX == 0) && from_hbm && mh >= 0 && mh < ncc;
+                unsigned long long bnd_bits = kSentinel;
+                const int bcol = kChunk * mh + lane;
+                const bool bwant = poll && lane < kChunk && bcol < N;
+                if (bwant) bnd_bits = load_sc1(bnd_in + bcol);
+                // ---- costs of the columns the DP wave sweeps into during its next chunk
+#ifdef RTS_SDP_STAMPS
+                const long long sh_a = (long long)__builtin_amdgcn_s_memtime();
+#endif
+                if (mh >= 0 && mh < ncc) {
+                    const int c0 = kChunk * mh;
+                    const int r0 = (c0 + lane) % kRing;  // ring step of (column c0, my row)
+                    const double2 *recs = reinterpret_cast<const double2 *>(yst + (size_t)(mh & 1) * kChunk * kYRec);
+                    static_for<0, kChunk>([&](auto kc) {
+                        constexpr int kk = decltype(kc)::value;  // column within the chunk
+                        if constexpr (helper_takes_column(H, HIDX, kk, P::kHelper0Cols)) {
+                        const double2 *rec = recs + (size_t)kk * (kYRec / 2);  // same address in every lane
+                        double y[kF];
+#pragma unroll
+                        for (int f = 0; f < kF / 2; f++) {
+                            const double2 t = rec[f];
+                            y[2 * f] = t.x;
+                            y[2 * f + 1] = t.y;
+                        }
+                        const double ny = P::kNorm ? rec[kF / 2].x : 0.0;
+                        const double c = P::cost(x, nx, y, ny);
+                        int r = r0 + kk;
+                        r = (r >= kRing) ? r - kRing : r;
+                        cring[r * 64 + lane] = c;
+                        }
+                    });
+                }
+#ifdef RTS_SDP_STAMPS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const long long sh_b = (long long)__builtin_amdgcn_s_memtime();
+                sh_cost += sh_b - sh_a;
+#endif
+                // ---- the DP wave's previous chunk leaves LDS: accumulated costs, a third of the tile per helper
+                const int mf = k - 2 - kLag * sidx;
+                if (STAGE && mf >= 0 && mf < nch) {
+                    // lane = (row within a group of 8, pair of columns): two doubles per lane, 16-byte stores (8-byte
+                    // aligned: the segment of row r starts at column 16 mf - r)
+                    const double *t = tile_mine + (size_t)(mf % kTiles) * kChunk * kStageLd;
+                    // all LDS reads first, then the stores: a store does not wait behind an LDS round trip
+                    double v0[8], v1[8];
+                    static_for<0, 8>([&](auto itc) {
+                        constexpr int it = decltype(itc)::value;
+                        if constexpr (helper_takes_rows(H, HIDX, it)) {
+                            const int r = it * 8 + (lane >> 3), q0 = 2 * (lane & 7);
+                            v0[it] = t[q0 * kStageLd + r];
+                            v1[it] = t[(q0 + 1) * kStageLd + r];
+                        }
+                    });
+                    static_for<0, 8>([&](auto itc) {
+                        constexpr int it = decltype(itc)::value;
+                        if constexpr (helper_takes_rows(H, HIDX, it)) {
+                            const int r = it * 8 + (lane >> 3), q0 = 2 * (lane & 7);
+                            const int row = strip * 64 + r, col = kChunk * mf + q0 - r;
+                            double *dst = pb.D + (size_t)row * pb.ldD + col;
+                            const bool ok0 = row < M && col >= 0 && col < N, ok1 = row < M && col + 1 >= 0 && col + 1 < N;
+                            if (ok0 && ok1) {
+                                // one 16-byte store at an 8-byte aligned address (global memory takes it; the
+                                // compiler would split it into two 8-byte stores)
+                                typedef double dpair __attribute__((ext_vector_type(2)));
+                                const dpair pv = {v0[it], v1[it]};
+                                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(pv) : "memory");
+                            } else {  // the two ends of a row
+                                if (ok0) dst[0] = v0[it];
+                                if (ok1) dst[1] = v1[it];
+                            }
+                        }
+                    });
+                }
+                // ---- helper 0: where did the best path of every cell of that chunk enter the strip?  The recurrence
+                //      needs nothing but the step codes: a cell hands on the entry column of the predecessor it chose;
+                //      lane 0's upper neighbours are in the row above, so their entry column is their own column
+                //      (16 mf + q for "up", one less for "diagonal" = what lane 0 received as ent_up one step earlier)
+                if (HIDX == 0 && mf >= 0 && mf < nch) {
+                    const uint32_t cw = codes_l[(mf & 1) * 64 + lane];
+                    int ecollect = 0;  // lane q: the entry column of lane 63 at step q (bottom row, column 16 mf + q - 63)
+                    static_for<0, kChunk>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        // code bits as lane masks (kLeft = 00, kUp = 01, kDiag = 10): bit-selects instead of
+                        // compare-and-select, which the compiler would turn into branches here
+                        const int m_up = ((int)(cw << (31 - 2 * q))) >> 31;    // -1 where the code is kUp
+                        const int m_dg = ((int)(cw << (30 - 2 * q))) >> 31;    // -1 where the code is kDiag
+                        const int ent_up = shr1_i(ent, kChunk * mf + q);
+                        const int from_above = (ent_up & m_up) | (ent_upprev & ~m_up);
+                        const int m_ab = m_up | m_dg;
+                        ent = (from_above & m_ab) | (ent & ~m_ab);
+                        ent_upprev = ent_up;
+                        const int el = __builtin_amdgcn_readlane(ent, 63);
+                        int &ec = ecollect;  // (an asm operand alone does not make the generic lambda capture it)
+                        asm("v_writelane_b32 %0, %1, %2" : "+v"(ec) : "s"(el), "n"(q));
+                    });
+                    const int col = kChunk * mf - 63 + lane;
+                    if (lane < kChunk && col >= 0 && col < N) pb.entb[(size_t)strip * N + col] = ecollect;
+                }
+                if (pre) commit_records(mh + 1);
+                if (poll) {  // wave-uniform
+                    int spins = 0;
+                    while (!dead && __any(bwant && bnd_bits == kSentinel)) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (bwant && bnd_bits == kSentinel) bnd_bits = load_sc1(bnd_in + bcol);
+                        if (++spins > kSpinLimit) {
+                            dead = true;
+                            if (lane == 0) atomicExch(pb.err, 1);
+                        }
+                    }
+                    if (lane < kChunk) upin[(mh & 1) * kChunk + lane] = __longlong_as_double((long long)bnd_bits);
+                }
+#ifdef RTS_SDP_STAMPS
+                sh_flush += (long long)__builtin_amdgcn_s_memtime() - sh_b;
+#endif
+            }
+#ifdef RTS_SDP_STAMPS
+            const long long sh_c = (long long)__builtin_amdgcn_s_memtime();
+            lds_barrier();
+            sh_bar += (long long)__builtin_amdgcn_s_memtime() - sh_c;
+#else
+            lds_barrier();
+#endif
+        }
+        };
+        if (hidx == 0)
+            helper_main(IntC<0>());
+        else if (hidx == 1)
+            helper_main(IntC<1>());
+        else
+            helper_main(IntC<(H > 2 ? 2 : 1)>());
+#ifdef RTS_SDP_STAMPS
+        if (rg == RTS_SDP_STAMPS && sidx == 0 && lane == 0) {
+            long long *dbg = reinterpret_cast<long long *>(pb.err) + 8 + 4 * hidx;
+            dbg[0] = sh_cost;
+            dbg[1] = sh_flush;
+            dbg[2] = sh_bar;
+        }
+#endif
+        return;
+    }
 
+    // ==================================== DP wave ==================================================================
+#ifdef RTS_SDP_STAMPS
+    long long st_steps = 0, st_bar = 0, st_all0 = (long long)__builtin_amdgcn_s_memtime(), st_n = 0;
+#endif
+    // The DP wave issues no vector-memory loads at all: its stores (step codes, the row handed to the next row group)
+    // are fire-and-forget and it never waits on vmcnt.
     double prev = 0.0, upprev = 0.0;
-    int ent = 0, ent_upprev = 0;  // entry column (see Problem::entb) of my previous cell / of the cell diagonally above it
-    int yslot = (lane == 0) ? 0 : YR - lane;  // ring slot of column 16m - lane at m = 0
-    unsigned long long next_bits = kSentinel;
-    bool dead = false;
-    if (from_hbm && lane < kChunk && lane < N) next_bits = load_sc1(bnd_in + lane);
-
-    for (int k = 0; k < total; k++) {
-        const int m = k - kLag * wave;  // my strip's chunk
+    for (int k = -1; k < total; k++) {
+        const int m = k - 1 - kLag * sidx;  // my strip's chunk
         if (strip_ok && m >= 0 && m < nch) {
             // ---- the row above, columns [16m, 16m+16): lane q holds column 16m+q
             double upbuf = 0.0;
             if (from_hbm) {
-                const int col = kChunk * m + lane;
-                const bool want = lane < kChunk && col < N;
-                unsigned long long v = next_bits;
-                int spins = 0;
-                while (!dead && __any(want && v == kSentinel)) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (want && v == kSentinel) v = load_sc1(bnd_in + col);
-                    if (++spins > kSpinLimit) {
-                        dead = true;
-                        if (lane == 0) atomicExch(pb.err, 1);
-                    }
+                if (lane < kChunk) upbuf = upin[(m & 1) * kChunk + lane];
+            } else if (sidx > 0) {
+                // the strip above finished column c at its step c + 63: chunk (c + 63) >> 4, row (c + 63) & 15 of
+                // its tiles, lane 63
+                if (lane < kChunk) {
+                    const int t = kChunk * m + lane + 63;
+                    upbuf = tile_up[(size_t)((t >> 4) % kTiles) * kChunk * kStageLd + (t & 15) * kStageLd + 63];
                 }
-                upbuf = __longlong_as_double((long long)v);
-                const int ncol = col + kChunk;
-                next_bits = kSentinel;
-                if (lane < kChunk && ncol < N) next_bits = load_sc1(bnd_in + ncol);  // consumed one chunk later
-            } else if (wave > 0) {
-                if (lane < kChunk) upbuf = bring_up[(kChunk * m + lane) & (kBRing - 1)];
             }
             const int jneg = lane - kChunk * m;  // column of step q is q - jneg
-            const double *ybase = yring + (size_t)yslot * kYRec;
+            const double *cbase = cring + (size_t)((kChunk * m) % kRing) * 64 + lane;
+            double *tile_w = tile_mine + (size_t)(m % kTiles) * kChunk * kStageLd + lane;
             uint32_t codes = 0;
-            double collect = 0.0;  // lane q: my lane 63's value of step q (bottom row, column 16m + q - 63)
-            int ecollect = 0;      // the same for its entry column
 
             // 16 branch-free steps.  FIRST: this strip holds matrix row 0 (lane 0); COL0: some lane is at column 0.
             auto steps = [&](auto first_c, auto col0_c) {
                 constexpr bool FIRST = decltype(first_c)::value;
                 constexpr bool COL0 = decltype(col0_c)::value;
                 const bool first_row = FIRST && lane == 0;
-                auto cost_of = [&](int q) {
-                    const double2 *rec = reinterpret_cast<const double2 *>(ybase + q * kYRec);
-                    double y[kF];
-#pragma unroll
-                    for (int t = 0; t < kF / 2; t++) {
-                        const double2 r = rec[t];
-                        y[2 * t] = r.x;
-                        y[2 * t + 1] = r.y;
-                    }
-                    double ny = 0.0;
-                    if (P::kNorm) ny = rec[kF / 2].x;
-                    return P::cost(x, nx, y, ny);
-                };
-                double c = cost_of(0);
+                // the chunk's 16 costs were produced during the previous chunk: fetch them all now, so that no step
+                // waits for an LDS round trip
+                double cst[kChunk];
                 static_for<0, kChunk>([&](auto qc) {
                     constexpr int q = decltype(qc)::value;
-                    double cn = 0.0;
-                    if (q + 1 < kChunk) cn = cost_of(q + 1);  // independent of this step's recurrence
+                    cst[q] = cbase[q * 64];
+                });
+                static_for<0, kChunk>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const double c = cst[q];
                     const double up = shr1(prev, readlane_d(upbuf, q));
                     double dv;
                     int code;
@@ -351,28 +545,14 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
                     prev = dv;
                     codes |= (uint32_t)code << (2 * q);
                     asm("" : "+v"(codes));  // materialise now: do not keep 48 lane masks alive
-                    // where did this cell's best path enter the strip?  Lane 0's upper neighbours are in the row above:
-                    // the entry column is that neighbour's own column (16m + q for "up", one less for "diagonal", which is
-                    // exactly what lane 0 received as ent_up one step earlier)
-                    const int ent_up = shr1_i(ent, kChunk * m + q);
-                    ent = (code == kLeft) ? ent : ((code == kUp) ? ent_up : ent_upprev);
-                    ent_upprev = ent_up;
-                    {
-                        const int lo = __builtin_amdgcn_readlane(__double2loint(dv), 63);
-                        const int hi = __builtin_amdgcn_readlane(__double2hiint(dv), 63);
-                        const int el = __builtin_amdgcn_readlane(ent, 63);
-                        int clo = __double2loint(collect), chi = __double2hiint(collect);
-                        asm("v_writelane_b32 %0, %1, %2" : "+v"(clo) : "s"(lo), "n"(q));
-                        asm("v_writelane_b32 %0, %1, %2" : "+v"(chi) : "s"(hi), "n"(q));
-                        asm("v_writelane_b32 %0, %1, %2" : "+v"(ecollect) : "s"(el), "n"(q));
-                        collect = __hiloint2double(chi, clo);
-                    }
-                    if (STAGE) stage_w[q * kStageLd + lane] = dv;
-                    c = cn;
+                    tile_w[q * kStageLd] = dv;
                 });
             };
             const bool first_strip = (strip == 0);
             const bool col0 = (kChunk * m < 64);
+#ifdef RTS_SDP_STAMPS
+            const long long st_a = (long long)__builtin_amdgcn_s_memtime();
+#endif
             if (first_strip) {
                 if (col0)
                     steps(BoolC<true>(), BoolC<true>());
@@ -384,37 +564,39 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
                 else
                     steps(BoolC<false>(), BoolC<false>());
             }
-            yslot += kChunk;
-            if (yslot >= YR) yslot -= YR;
-
+#ifdef RTS_SDP_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            st_steps += (long long)__builtin_amdgcn_s_memtime() - st_a;
+            st_n++;
+#endif
             pb.codes[((size_t)strip * nch + m) * 64 + lane] = codes;
-            // bottom-row columns finished in this chunk: [16m - 63, 16m - 48], held by lanes 0..15 of `collect`
-            {
+            codes_l[(m & 1) * 64 + lane] = codes;
+            if (to_hbm) {  // bottom-row columns finished in this chunk: [16m - 63, 16m - 48] (my lane 63, steps 0..15)
                 const int col = kChunk * m - 63 + lane;
-                if (lane < kChunk) {
-                    bring_w[col & (kBRing - 1)] = collect;
-                    if (col >= 0 && col < N) {
-                        pb.entb[(size_t)strip * N + col] = ecollect;
-                        if (to_hbm) store_sc1(bnd_out + col, (unsigned long long)__double_as_longlong(collect));
-                    }
+                if (lane < kChunk && col >= 0 && col < N) {
+                    __builtin_amdgcn_wave_barrier();
+                    const double v = tile_mine[(size_t)(m % kTiles) * kChunk * kStageLd + lane * kStageLd + 63];
+                    store_sc1(bnd_out + col, (unsigned long long)__double_as_longlong(v));
                 }
-            }
-            if (STAGE) {
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int it = 0; it < kChunk; it++) {
-                    const int r = it * 4 + (lane >> 4), qq = lane & 15;
-                    const double v = stage_w[qq * kStageLd + r];
-                    const int row = strip * 64 + r, col = kChunk * m + qq - r;
-                    if (row < M && col >= 0 && col < N) pb.D[(size_t)row * pb.ldD + col] = v;
-                }
-                __builtin_amdgcn_wave_barrier();
             }
         }
-        // ---- column records for the next chunk (needed first by wave 0, lane 0)
-        if (wave == k % NW) stage_columns(kChunk * (k + 1));
+#ifdef RTS_SDP_STAMPS
+        const long long st_b = (long long)__builtin_amdgcn_s_memtime();
         lds_barrier();
+        st_bar += (long long)__builtin_amdgcn_s_memtime() - st_b;
+#else
+        lds_barrier();
+#endif
     }
+#ifdef RTS_SDP_STAMPS
+    if (rg == RTS_SDP_STAMPS && sidx == 0 && lane == 0) {
+        long long *dbg = reinterpret_cast<long long *>(pb.err) + 2;
+        dbg[0] = st_steps;
+        dbg[1] = st_bar;
+        dbg[2] = (long long)__builtin_amdgcn_s_memtime() - st_all0;
+        dbg[3] = st_n;
+    }
+#endif
 }
 
 // ---- backtrack over the packed, skewed step codes ----------------------------------------------------------------

@@ -52,8 +52,9 @@ struct WtwArgs {
     unsigned long long *bnd;   // [B][n_strips(W)][W] rows handed between row groups
     int32_t *entb;             // [B][n_strips(W)][W] entry columns of the strips' bottom rows (sdp.h)
     int32_t *cross, *lens;     // [B][n_strips(W)] strip-boundary crossings / segment lengths of the window's path
+    double *yrec;              // [B][W][14] prepared records of the window's reference columns
     int32_t *err;
-    int n_rg;
+    int n_rg, n_strips_wg;
     int M, N, W, hopf, path_cap;
 };
 
@@ -257,18 +258,18 @@ __global__ void __launch_bounds__(256) wtw_advance_kernel(WtwArgs g) {
 
 // ---- windows of more than kWtwLdsW frames: strip DP over many workgroups (sdp.h) ------------------------------
 
-template <bool STAGE>
-__global__ void __launch_bounds__(512) wtw_big_dp_kernel(WtwArgs g) {
+// H helper waves per strip: <.., 2> two strips per workgroup, <.., 3> one strip per workgroup (sdp::pick_config).
+template <bool STAGE, int H>
+__global__ void __launch_bounds__(H == 2 ? 384 : 256) wtw_big_dp_kernel(WtwArgs g) {
     extern __shared__ __align__(16) unsigned char wtw_smem[];
     const int b = blockIdx.y;
     const int32_t *ctl = g.ctl + (size_t)b * 8;
     if (ctl[0] == 0) return;  // no window pending for this stream
-    const int lp = ctl[1], rp = ctl[2];
+    const int lp = ctl[1];
     sdp::Problem pb;
     pb.x = g.live + ((size_t)b * g.N + lp) * kWF;  // rows: the live window (wtw.py:101)
-    pb.y = g.ref + (size_t)rp * kWF;               // columns: the reference window (wtw.py:102)
     pb.x_f64 = 1;
-    pb.y_f64 = 1;
+    pb.yrec = g.yrec + (size_t)b * g.W * sdp::kYRec;  // columns: the reference window (wtw.py:102), prepared by ctl
     pb.M = ctl[3];
     pb.N = ctl[4];
     pb.D = STAGE ? g.dlast + (size_t)b * g.W * g.W : nullptr;
@@ -277,8 +278,8 @@ __global__ void __launch_bounds__(512) wtw_big_dp_kernel(WtwArgs g) {
     pb.bnd = g.bnd + (size_t)b * sdp::n_strips(g.W) * g.W;
     pb.entb = g.entb + (size_t)b * sdp::n_strips(g.W) * g.W;
     pb.err = g.err;
-    const int NW = blockDim.x >> 6;
-    for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x) sdp::run_rowgroup<sdp::WtwPolicy, STAGE>(pb, rg, g.n_rg, NW, wtw_smem);
+    for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x)
+        sdp::run_rowgroup<sdp::WtwPolicy, STAGE, H>(pb, rg, g.n_rg, g.n_strips_wg, wtw_smem);
 }
 
 // find_path (wtw.py:219-240) for the pending window of each stream, over the packed step codes (sdp.h): the
@@ -377,6 +378,9 @@ __global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) {
         unsigned long long *bnd = g.bnd + (size_t)b * sdp::n_strips(W) * W;
         const size_t words = (size_t)(g.n_rg > 1 ? g.n_rg - 1 : 0) * nm;
         for (size_t k = tid; k < words; k += NT) bnd[k] = sdp::kSentinel;
+        for (int col = tid; col < nm; col += NT)  // the window's reference columns as float64 records with their norms
+            sdp::prep_column<sdp::WtwPolicy>(g.ref, 1, (long long)ref_ptr + col,
+                                             g.yrec + (size_t)b * W * sdp::kYRec - (size_t)ref_ptr * sdp::kYRec);
     }
     __syncthreads();
     if (tid == 0) {
@@ -440,9 +444,10 @@ struct rts_wtw {
     int8_t *bwork;
     double *dlast;
     int32_t *ws_sub, *ctl, *err, *entb, *cross, *lens;
+    double *yrec;
     uint32_t *codes;
     unsigned long long *bnd;
-    int big_waves, n_rg, big_grid;
+    int big_waves, big_helpers, n_rg, big_grid;
     size_t smem;
 };
 
@@ -473,17 +478,13 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     const int W = win_frames;
     const bool big = W > kWtwLdsW;
     if (big) {
-        const char *env = getenv("RTS_SDP_WAVES");  // tuning knob; results do not depend on it
-        int nw = env ? atoi(env) : 4;
-        if (nw < 1) nw = 1;
-        if (nw > sdp::kMaxWaves) nw = sdp::kMaxWaves;
+        int nw, nh, grid;
+        sdp::pick_config(sdp::n_strips(W), B, nw, nh, grid);
         h->big_waves = nw;
+        h->big_helpers = nh;
         h->n_rg = (sdp::n_strips(W) + nw - 1) / nw;
-        int grid = 256 / B;  // every workgroup of a stream's pipeline must be resident: at most one per CU
-        if (grid < 1) grid = 1;
-        if (grid > h->n_rg) grid = h->n_rg;
         h->big_grid = grid;
-        h->smem = sdp::lds_bytes(nw, keep_last_d != 0);
+        h->smem = sdp::lds_bytes(nw);
     } else {
         h->smem = sizeof(double) * ((size_t)2 * W * kWF + 2 * W + 3 * W) + sizeof(int32_t) * 4 * W +
                   (W <= kWtwLdsB ? (size_t)W * W : 0) + 64;
@@ -501,15 +502,20 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         (big && (e = hipMalloc((void **)&h->bnd, sizeof(unsigned long long) * (size_t)sdp::n_strips(W) * W * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->entb, sizeof(int32_t) * (size_t)sdp::n_strips(W) * W * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->cross, sizeof(int32_t) * (size_t)sdp::n_strips(W) * B)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->yrec, sizeof(double) * sdp::kYRec * (size_t)W * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->lens, sizeof(int32_t) * (size_t)sdp::n_strips(W) * B)) != hipSuccess) ||
         (keep_last_d && (e = hipMalloc((void **)&h->dlast, sizeof(double) * (size_t)B * W * W)) != hipSuccess) ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess ||
         (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_advance_kernel<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<true>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<true, 2>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<false>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<false, 2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<true, 3>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<false, 3>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) {
         rts_wtw_destroy(h);
         return set_error(RTS_ERR_HIP, "WTW allocation failed: %s", hipGetErrorString(e));
@@ -542,6 +548,7 @@ int rts_wtw_destroy(rts_wtw *h) {
     if (h->bnd) (void)hipFree(h->bnd);
     if (h->entb) (void)hipFree(h->entb);
     if (h->cross) (void)hipFree(h->cross);
+    if (h->yrec) (void)hipFree(h->yrec);
     if (h->lens) (void)hipFree(h->lens);
     free(h);
     return RTS_OK;
@@ -591,8 +598,10 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.entb = h->entb;
     g.cross = h->cross;
     g.lens = h->lens;
+    g.yrec = h->yrec;
     g.err = h->err;
     g.n_rg = h->n_rg;
+    g.n_strips_wg = h->big_waves;
     g.M = h->M;
     g.N = h->N;
     g.W = h->W;
@@ -604,10 +613,18 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
         const int rounds = n_max / h->hopf + 1;
         hipLaunchKernelGGL(wtw_big_ctl_kernel, dim3(h->B), dim3(1024), 0, s, g);
         for (int r = 0; r < rounds; r++) {
-            if (h->dlast)
-                hipLaunchKernelGGL((wtw_big_dp_kernel<true>), dim3(h->big_grid, h->B), dim3(64 * h->big_waves), h->smem, s, g);
-            else
-                hipLaunchKernelGGL((wtw_big_dp_kernel<false>), dim3(h->big_grid, h->B), dim3(64 * h->big_waves), h->smem, s, g);
+            const dim3 grid(h->big_grid, h->B), block(64 * h->big_waves * (1 + h->big_helpers));
+            if (h->big_helpers == 2) {
+                if (h->dlast)
+                    hipLaunchKernelGGL((wtw_big_dp_kernel<true, 2>), grid, block, h->smem, s, g);
+                else
+                    hipLaunchKernelGGL((wtw_big_dp_kernel<false, 2>), grid, block, h->smem, s, g);
+            } else {
+                if (h->dlast)
+                    hipLaunchKernelGGL((wtw_big_dp_kernel<true, 3>), grid, block, h->smem, s, g);
+                else
+                    hipLaunchKernelGGL((wtw_big_dp_kernel<false, 3>), grid, block, h->smem, s, g);
+            }
             hipLaunchKernelGGL(wtw_big_hops_kernel, dim3(h->B), dim3(64), 0, s, g);
             hipLaunchKernelGGL((wtw_big_segment_kernel<0>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
             hipLaunchKernelGGL((wtw_big_segment_kernel<1>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
