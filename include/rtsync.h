@@ -240,7 +240,7 @@ typedef struct rts_wtw rts_wtw;
 /* Replaces the chroma-level state of WTW.__init__ (wtw.py:50-68): `chroma_ref_dev` is the reference
  * chroma [M][F] float64 (what wtw.py:37-41 computes; use rts_chroma_frames with pad_left =
  * fft_len/2), held by reference.  win_frames = dtw_win_size / hop_size, hop_frames = dtw_hop_size /
- * hop_size (wtw.py:100,:107), 1 <= win_frames <= 16384 (one workgroup per stream up to 512 frames; a
+ * hop_size (wtw.py:100,:107), 1 <= win_frames <= 16384 (one workgroup per stream up to 64 frames; a
  * pipeline of workgroups per window above), hop_frames >= 1.  The handle owns a live
  * chroma history of 2M frames per stream (wtw.py:52,:55).  keep_last_d != 0 also keeps the last
  * window's accumulated-cost matrix D for inspection (the reference stores it into self.acc_cost,

@@ -13,8 +13,8 @@
 //      l <= dtw_hop/hop, move (live_ptr, ref_ptr) to the last appended point) on one lane.
 // The back-pointer matrix lives in LDS for W <= 128 and in an HBM workspace above that.
 //
-// Windows of more than 512 frames (BASELINE configs[4]: W = 10 000) are a different regime -- one window is
-// 1e8 cells -- and run as a strip DP (sdp.h) spread over many workgroups: per window one launch of
+// Windows of more than 64 frames (wtw_live.py's W = 100 up to BASELINE configs[4]'s W = 10 000, where one window is
+// 1e8 cells) run as a strip DP (sdp.h) spread over many workgroups: per window one launch of
 // wtw_big_dp_kernel (a pipeline of row groups down the W x W matrix, step codes packed 2 bits per cell), the
 // backtrack kernels (wtw_big_hops_kernel, wtw_big_segment_kernel: every strip's path segment by its own wave) and
 // wtw_big_ctl_kernel (hand-over, then the column bookkeeping of
@@ -35,6 +35,7 @@ constexpr int kWF = 12;
 constexpr int kWtwNT = 256;
 constexpr int kWtwLdsB = 128;  // largest W whose back-pointers stay in LDS
 constexpr int kWtwLdsW = 512;  // largest W whose window (features, norms, diagonals) stays in LDS
+constexpr int kWtwStripFrom = 64;  // windows above this many frames use the strip DP (sdp.h)
 constexpr int kWtwMaxW = 16384;
 
 struct WtwArgs {
@@ -447,7 +448,7 @@ struct rts_wtw {
     double *yrec;
     uint32_t *codes;
     unsigned long long *bnd;
-    int big_waves, big_helpers, n_rg, big_grid;
+    int big_waves, big_helpers, n_rg, big_grid, use_big;
     size_t smem;
 };
 
@@ -476,7 +477,13 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     h->hopf = hop_frames;
     h->path_cap = (h->N / hop_frames + 2) * (win_frames + hop_frames + 2);
     const int W = win_frames;
-    const bool big = W > kWtwLdsW;
+    // Windows of more than one strip (64 rows) take the strip-DP path: measured on 64 streams at wtw_live.py's W = 100 /
+    // hop = 50 it is twice as fast as the single-workgroup sweep despite its five launches per window.
+    // RTS_WTW_BIG_FROM overrides the threshold (tuning and tests; results do not depend on it).
+    int big_from = kWtwStripFrom;
+    if (const char *e = getenv("RTS_WTW_BIG_FROM")) big_from = atoi(e) < kWtwLdsW ? atoi(e) : kWtwLdsW;
+    const bool big = W > big_from;
+    h->use_big = big;
     if (big) {
         int nw, nh, grid;
         sdp::pick_config(sdp::n_strips(W), B, nw, nh, grid);
@@ -607,7 +614,7 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.W = h->W;
     g.hopf = h->hopf;
     g.path_cap = h->path_cap;
-    if (h->W > kWtwLdsW) {
+    if (h->use_big) {
         // one (dp, ctl) round per window the new columns can complete: the first needs at least one column, every
         // further one dtw_hop / hop more (the live pointer advances by exactly that per window, wtw.py:118-128)
         const int rounds = n_max / h->hopf + 1;
