@@ -3,7 +3,8 @@
 // Reference: /root/reference/chroma.py:35-90 (create_stft, create_chroma, wav_to_chroma_col,
 // wav_to_chroma_diff) and the per-hop half of wtw.WTW (wtw.py:37-41, :81-90).
 //
-//   chroma_frames_kernel   one workgroup (256 threads) per frame, persistent over frames:
+//   chroma_frames_kernel   one team of 256 threads per frame, two teams (two frames in flight) per workgroup,
+//                          persistent over groups of four frames:
 //       1. L samples (zero-padded on the left by `pad_left`, chroma.py:49) x window -> LDS as L/2
 //          packed complex float64 (even sample = re, odd = im);
 //       2. L/2-point complex Stockham radix-4 (+ one radix-2 stage) FFT in LDS (float64; twiddles exp(-2 pi i n / L),
@@ -57,48 +58,71 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 }
 
 constexpr int kChromaFR = 4;  // frames sharing one pass over the filterbank
+#ifdef RTS_CHROMA_STAMPS
+__device__ long long g_chroma_stamps[8];
+#define CH_STAMP(i)                                                        \
+    do {                                                                   \
+        const long long now_ = (long long)__builtin_amdgcn_s_memtime();    \
+        if (threadIdx.x == 0 && blockIdx.x == 0) st_[i] += now_ - last_;   \
+        last_ = now_;                                                      \
+    } while (0)
+#else
+#define CH_STAMP(i) \
+    do {            \
+    } while (0)
+#endif
 
-// Steps 4-5 for NF <= kChromaFR frames whose power spectra sit in LDS (spec + f*spec_stride).
-// Each thread owns bins k = tid (mod 256) and keeps 12 running sums per frame, so the 197 KB
-// filterbank is read from L2 once per NF frames.  The 12 x 256 partial sums of a frame are then
-// reduced through LDS (`red`: [12][256] doubles): 192 threads add 16 each, 12 threads add the 16
-// partials in index order -- a fixed summation order, independent of NF.
+// Steps 4-5 for up to kProjMax frames whose power spectra sit in LDS: frames f = f_first + i * f_step (i < kProjMax)
+// with f < nf, spectrum at spec + f * spec_stride, output frame frame0 + f.  One team of 256 threads (`tid` is the
+// index within the team; `bar` synchronises at least the team): each thread owns bins k = tid (mod 256) and keeps 12
+// running sums per frame, so the 197 KB filterbank is read from L2 once per call.  The 12 x 256 partial sums of a
+// frame are then reduced through LDS (`red`: [12][256] + 192 doubles): 192 threads add 16 each, 12 threads add the 16
+// partials in index order -- a fixed summation order, independent of how many frames share the pass.
+// Every thread executes every barrier, whatever nf is.
+template <int kProjMax, class Barrier>
 __device__ __forceinline__ void project_normalize(const ChromaArgs &g, const double *spec, int spec_stride,
-                                                  double *red, int frame0, int nf, int tid) {
+                                                  double *red, int frame0, int nf, int f_first, int f_step, int tid,
+                                                  Barrier bar) {
     const int nb = g.L / 2 + 1;
-    double acc[kChromaFR][kCh];
+    double acc[kProjMax][kCh];
 #pragma unroll
-    for (int f = 0; f < kChromaFR; f++)
+    for (int i = 0; i < kProjMax; i++)
 #pragma unroll
-        for (int p = 0; p < kCh; p++) acc[f][p] = 0.0;
-    for (int k = tid; k < nb; k += kChromaNT) {
-        double w[kCh];
+        for (int p = 0; p < kCh; p++) acc[i][p] = 0.0;
+    if (f_first < nf) {
+        for (int k = tid; k < nb; k += kChromaNT) {
+            double w[kCh];
 #pragma unroll
-        for (int p = 0; p < kCh; p++) w[p] = g.fb[(size_t)p * nb + k];
+            for (int p = 0; p < kCh; p++) w[p] = g.fb[(size_t)p * nb + k];
 #pragma unroll
-        for (int f = 0; f < kChromaFR; f++) {
-            if (f < nf) {
-                const double sv = spec[(size_t)f * spec_stride + k];
+            for (int i = 0; i < kProjMax; i++) {
+                const int f = f_first + i * f_step;
+                if (f < nf) {
+                    const double sv = spec[(size_t)f * spec_stride + k];
 #pragma unroll
-                for (int p = 0; p < kCh; p++) acc[f][p] = fma(w[p], sv, acc[f][p]);
+                    for (int p = 0; p < kCh; p++) acc[i][p] = fma(w[p], sv, acc[i][p]);
+                }
             }
         }
     }
 #pragma unroll
-    for (int f = 0; f < kChromaFR; f++) {
-        if (f >= nf) break;  // uniform
+    for (int i = 0; i < kProjMax; i++) {
+        const int f = f_first + i * f_step;
+        const bool live = f < nf;
+        if (live) {
 #pragma unroll
-        for (int p = 0; p < kCh; p++) red[p * kChromaNT + tid] = acc[f][p];
-        __syncthreads();
-        if (tid < kCh * 16) {
+            for (int p = 0; p < kCh; p++) red[p * kChromaNT + tid] = acc[i][p];
+        }
+        bar();
+        if (live && tid < kCh * 16) {
             const int p = tid >> 4, q = tid & 15;
             double sum = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; i++) sum = sum + red[p * kChromaNT + q * 16 + i];
+            for (int j = 0; j < 16; j++) sum = sum + red[p * kChromaNT + q * 16 + j];
             red[kCh * kChromaNT + tid] = sum;
         }
-        __syncthreads();
-        if (tid < 64) {  // wave 0: lane p < 12 finishes bin p (same order of additions as before), lane 0 the norm
+        bar();
+        if (live && tid < 64) {  // one wave: lane p < 12 finishes bin p, then every lane forms the norm
             double cp = 0.0;
             if (tid < kCh) {
 #pragma unroll
@@ -122,24 +146,38 @@ __device__ __forceinline__ void project_normalize(const ChromaArgs &g, const dou
                     reinterpret_cast<float *>(g.chroma_out)[(size_t)(frame0 + f) * kCh + tid] = (float)v;
             }
         }
-        __syncthreads();
+        bar();
     }
 }
 
-__global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) {
-    extern __shared__ __align__(16) unsigned char ch_smem[];
-    const int L = g.L, N2 = L / 2;
-    const int sstride = N2 + 2;                          // doubles per power spectrum in LDS
-    double2 *z = reinterpret_cast<double2 *>(ch_smem);   // [N2]   FFT work buffer; reused as reduction scratch
-    double2 *tw = z + N2;                                // [N2]
-    double *spec = reinterpret_cast<double *>(tw + N2);  // [kChromaFR][sstride]
-    // reduction scratch [12][256] + [192] doubles: the FFT buffer when it is large enough (it is free by
-    // then), a region of its own for short transforms
-    double *red = (2 * N2 >= 3264) ? reinterpret_cast<double *>(z) : spec + (size_t)kChromaFR * sstride;
-    const int tid = threadIdx.x;
+// Two teams of 256 threads per workgroup, each transforming its own frame (two waves per SIMD: the FFT is a chain of
+// short dependent phases -- LDS round trip, a few dozen flops, barrier -- and a second frame fills the gaps).  A group
+// of kChromaFR = 4 consecutive frames is handled in two rounds (team h takes frames h and h + 2) and each team then
+// projects its two spectra in one pass over the filterbank.
+constexpr int kChromaWG = 2 * kChromaNT;
 
-    for (int n = tid; n < N2; n += kChromaNT) tw[n] = g.twiddle[n];
+template <typename ST>  // sample type in HBM: float or double
+__global__ void __launch_bounds__(kChromaWG) chroma_frames_kernel(ChromaArgs g) {
+    extern __shared__ __align__(16) unsigned char ch_smem[];
+    const int L = g.L, N2 = L / 2, NQ = N2 / 2;
+    const int sstride = N2 + 2;                               // doubles per power spectrum in LDS
+    const int team = threadIdx.x >> 8, tid = threadIdx.x & (kChromaNT - 1);
+    double2 *zbase = reinterpret_cast<double2 *>(ch_smem);    // [2][N2] FFT work buffers, one per team
+    double2 *z = zbase + (size_t)team * N2;
+    double2 *twh = zbase + 2 * (size_t)N2;                    // [N2/2]  exp(-2 pi i n / L), n < L/4
+    double *spec = reinterpret_cast<double *>(twh + NQ);      // [kChromaFR][sstride]
+    // reduction scratch of a team ([12][256] + [192] doubles): its FFT buffer when that is large enough (it is free by
+    // then), a region of its own for short transforms
+    double *red = (2 * N2 >= 3264) ? reinterpret_cast<double *>(z)
+                                   : spec + (size_t)kChromaFR * sstride + (size_t)team * 3264;
+
+    // quarter-circle twiddle table; the second quarter follows by a rotation: exp(-i (x + pi/2)) = -i exp(-i x)
+    for (int n = threadIdx.x; n < NQ; n += kChromaWG) twh[n] = g.twiddle[n];
     __syncthreads();
+    auto tw = [&](int t) {  // t < N2
+        const double2 w = twh[t & (NQ - 1)];
+        return (t & NQ) ? make_double2(w.y, -w.x) : w;
+    };
 
     // batched launch: this workgroup's stream
     const int sb = blockIdx.y;
@@ -147,8 +185,7 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
         g.n_frames = g.n_frames_b[sb];
         g.n_samples = g.n_samples_b[sb];
         const long long so = (long long)sb * g.sample_stride;
-        g.samples = g.samples_f64 ? (const void *)(reinterpret_cast<const double *>(g.samples) + so)
-                                  : (const void *)(reinterpret_cast<const float *>(g.samples) + so);
+        g.samples = reinterpret_cast<const ST *>(g.samples) + so;
         const long long oo = (long long)sb * g.out_frames_stride * kCh;
         g.chroma_out = g.out_f64 ? (void *)(reinterpret_cast<double *>(g.chroma_out) + oo)
                                  : (void *)(reinterpret_cast<float *>(g.chroma_out) + oo);
@@ -164,31 +201,56 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
         win_im[r] = (n < N2) ? g.window[2 * n + 1] : 0.0;
     }
 
+    // Samples of the team's next frame, fetched one frame ahead.  Nothing is done to a loaded value in the frame that
+    // fetches it (not even float -> double): a use would make the wave wait for the load right there.  Branch-free:
+    // indices are clamped into the buffer; out-of-range positions (the zero padding on the left, the end of the
+    // signal, frames past the last one) are zeroed when the values are used.
+    ST ps0[kMaxPairs], ps1[kMaxPairs];
+#pragma unroll
+    for (int r = 0; r < kMaxPairs; r++) ps0[r] = ps1[r] = (ST)0;
+    auto clamp_idx = [&](long long idx) {
+        const long long hi = g.n_samples > 0 ? g.n_samples - 1 : 0;
+        return idx < 0 ? 0 : (idx > hi ? hi : idx);
+    };
+    auto fetch_frame = [&](long long frame) {
+        const long long s0 = g.frame_offset + frame * g.hop;
+#pragma unroll
+        for (int r = 0; r < kMaxPairs; r++) {
+            const int n = tid + r * kChromaNT;
+            ps0[r] = reinterpret_cast<const ST *>(g.samples)[clamp_idx(s0 + 2 * n)];
+            ps1[r] = reinterpret_cast<const ST *>(g.samples)[clamp_idx(s0 + 2 * n + 1)];
+        }
+    };
+    fetch_frame((long long)blockIdx.x * kChromaFR + team);
+#ifdef RTS_CHROMA_STAMPS
+    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long last_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
     for (int frame0 = blockIdx.x * kChromaFR; frame0 < g.n_frames; frame0 += gridDim.x * kChromaFR) {
         const int nf = (g.n_frames - frame0 < kChromaFR) ? g.n_frames - frame0 : kChromaFR;
-        for (int f = 0; f < nf; f++) {
+        for (int round = 0; round < kChromaFR / 2; round++) {
+            const int f = 2 * round + team;   // my team's frame within the group
             const int frame = frame0 + f;
-            // 1. load + window, packed as complex
-            const long long s0 = g.frame_offset + (long long)frame * g.hop;
+            const bool live = f < nf;         // team-uniform; a dead team still takes part in every barrier
+            CH_STAMP(0);
+            // 1. window the samples fetched one frame ago (registers), pack as complex; then fetch the team's next
+            //    frame: its HBM latency hides behind this frame's FFT
 #pragma unroll
             for (int r = 0; r < kMaxPairs; r++) {
                 const int n = tid + r * kChromaNT;
                 if (n >= N2) break;
-                const long long s = s0 + 2 * n;
-                double x0 = 0.0, x1 = 0.0;
-                if (s >= 0 && s < g.n_samples)
-                    x0 = g.samples_f64 ? reinterpret_cast<const double *>(g.samples)[s]
-                                       : (double)reinterpret_cast<const float *>(g.samples)[s];
-                if (s + 1 >= 0 && s + 1 < g.n_samples)
-                    x1 = g.samples_f64 ? reinterpret_cast<const double *>(g.samples)[s + 1]
-                                       : (double)reinterpret_cast<const float *>(g.samples)[s + 1];
+                const long long sidx = g.frame_offset + (long long)frame * g.hop + 2 * n;
+                const double x0 = (sidx >= 0 && sidx < g.n_samples) ? (double)ps0[r] : 0.0;
+                const double x1 = (sidx + 1 >= 0 && sidx + 1 < g.n_samples) ? (double)ps1[r] : 0.0;
                 z[n] = make_double2(x0 * win_re[r], x1 * win_im[r]);
             }
-            __syncthreads();
+            fetch_frame(round + 1 < kChromaFR / 2 ? (long long)frame + 2
+                                                  : (long long)frame0 + (long long)gridDim.x * kChromaFR + team);
+            lds_barrier();  // LDS traffic only: the sample prefetch stays in flight
+            CH_STAMP(1);
             // 2. Stockham autosort FFT, N2 points, in place via registers (read all, barrier, write all): one radix-2
-            //    stage when log2(N2) is odd, then radix-4 stages -- 6 stages / 12 barriers for L = 4096 instead of 11 / 22
-            //    and half the LDS traffic.  Stage with sub-transform length p: butterfly i = s*p + k reads i + m*N2/r
-            //    (m < r), twiddles exp(-2 pi i k m / (r p)) = tw[k m N2 / (r p / 2)], writes s*(r p) + k + m*p.
+            //    stage when log2(N2) is odd, then radix-4 stages.  Stage with sub-transform length p: butterfly
+            //    i = s*p + k reads i + m*N2/r (m < r), twiddles exp(-2 pi i k m / (r p)), writes s*(r p) + k + m*p.
             int p = 1;
             if ((31 - __clz(N2)) & 1) {  // log2(N2) odd
                 const int half = N2 / 2;
@@ -203,7 +265,7 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
                         o1[r] = make_double2(u0.x - u1.x, u0.y - u1.y);
                     }
                 }
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int r = 0; r < kMaxBf; r++) {
                     const int i = tid + r * kChromaNT;
@@ -212,7 +274,7 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
                         z[2 * i + 1] = o1[r];
                     }
                 }
-                __syncthreads();
+                lds_barrier();
                 p = 2;
             }
             const int q = N2 / 4;
@@ -227,8 +289,8 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
                     if (i < q) {
                         const int k = i & (p - 1);
                         const int t1 = k * tstep, t2 = 2 * t1, t3 = 3 * t1;  // t1 < N2/2, t2 < N2, t3 < 3 N2/2
-                        const double2 w1 = tw[t1], w2 = tw[t2];
-                        double2 w3 = tw[t3 & (N2 - 1)];
+                        const double2 w1 = tw(t1), w2 = tw(t2);
+                        double2 w3 = tw(t3 & (N2 - 1));
                         if (t3 >= N2) w3 = make_double2(-w3.x, -w3.y);  // exp(-i (pi + x)) = -exp(-i x)
                         const double2 u0 = z[i];
                         const double2 u1 = cmul(w1, z[i + q]);
@@ -245,7 +307,7 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
                         jj[r] = ((i - k) << 2) + k;
                     }
                 }
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int r = 0; r < kMaxBf4; r++) {
                     const int i = tid + r * kChromaNT;
@@ -256,29 +318,40 @@ __global__ void __launch_bounds__(kChromaNT) chroma_frames_kernel(ChromaArgs g) 
                         z[jj[r] + 3 * p] = o[r][3];
                     }
                 }
-                __syncthreads();
+                lds_barrier();
             }
+            CH_STAMP(2);
             // 3. untangle: X[k] = E[k] + W_L^k O[k], E = (Z[k] + conj Z[N2-k]) / 2, O = (Z[k] - conj Z[N2-k]) / (2i)
             const int nb = N2 + 1;
             double *sp = spec + (size_t)f * sstride;
-            for (int k = tid; k < nb; k += kChromaNT) {
-                const double2 a = z[k & (N2 - 1)];          // Z[N2] == Z[0]
-                const double2 bq = z[(N2 - k) & (N2 - 1)];
-                const double2 b = make_double2(bq.x, -bq.y);  // conj
-                const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
-                const double2 dm = make_double2(a.x - b.x, a.y - b.y);
-                const double2 o = make_double2(0.5 * dm.y, -0.5 * dm.x);  // dm / (2i)
-                const double2 w = (k < N2) ? tw[k] : make_double2(-1.0, 0.0);
-                const double2 wo = cmul(w, o);
-                const double2 x = make_double2(e.x + wo.x, e.y + wo.y);
-                if (g.stft_out) g.stft_out[(size_t)frame * nb + k] = x;
-                sp[k] = x.x * x.x + x.y * x.y;
+            if (live) {
+                for (int k = tid; k < nb; k += kChromaNT) {
+                    const double2 a = z[k & (N2 - 1)];          // Z[N2] == Z[0]
+                    const double2 bq = z[(N2 - k) & (N2 - 1)];
+                    const double2 b = make_double2(bq.x, -bq.y);  // conj
+                    const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+                    const double2 dm = make_double2(a.x - b.x, a.y - b.y);
+                    const double2 o = make_double2(0.5 * dm.y, -0.5 * dm.x);  // dm / (2i)
+                    const double2 w = (k < N2) ? tw(k) : make_double2(-1.0, 0.0);
+                    const double2 wo = cmul(w, o);
+                    const double2 x = make_double2(e.x + wo.x, e.y + wo.y);
+                    if (g.stft_out) g.stft_out[(size_t)frame * nb + k] = x;
+                    sp[k] = x.x * x.x + x.y * x.y;
+                }
             }
-            __syncthreads();
+            lds_barrier();
+            CH_STAMP(3);
         }
-        // 4-5 for the whole group (z is free now and serves as reduction scratch)
-        if (g.chroma_out) project_normalize(g, spec, sstride, red, frame0, nf, tid);
+        // 4-5: each team projects its frames (f = team, team + 2) in one pass over the filterbank; its own FFT buffer
+        //      is free now and serves as reduction scratch
+        if (g.chroma_out)
+            project_normalize<kChromaFR / 2>(g, spec, sstride, red, frame0, nf, team, 2, tid, [] { lds_barrier(); });
+        CH_STAMP(4);
     }
+#ifdef RTS_CHROMA_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 8; i++) g_chroma_stamps[i] = st_[i];
+#endif
 }
 
 __global__ void __launch_bounds__(kChromaNT) chroma_project_kernel(ChromaArgs g) {
@@ -293,7 +366,7 @@ __global__ void __launch_bounds__(kChromaNT) chroma_project_kernel(ChromaArgs g)
         for (int f = 0; f < nf; f++)
             for (int k = tid; k < nb; k += kChromaNT) spec[(size_t)f * sstride + k] = g.spec_in[(size_t)(frame0 + f) * nb + k];
         __syncthreads();
-        project_normalize(g, spec, sstride, red, frame0, nf, tid);
+        project_normalize<kChromaFR>(g, spec, sstride, red, frame0, nf, 0, 1, tid, [] { __syncthreads(); });
     }
 }
 
@@ -369,12 +442,15 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
     }
     free(win);
     free(tw);
-    h->smem_frames = sizeof(double2) * 2 * N2 + sizeof(double) * (size_t)kChromaFR * (N2 + 2) +
-                     ((2 * N2 >= 3264) ? 0 : sizeof(double) * 3264) + 64;
+    h->smem_frames = sizeof(double2) * (2 * (size_t)N2 + N2 / 2) + sizeof(double) * (size_t)kChromaFR * (N2 + 2) +
+                     ((2 * N2 >= 3264) ? 0 : sizeof(double) * 2 * 3264) + 64;
     h->smem_project = sizeof(double) * ((size_t)kChromaFR * (nb + 1) + 3264) + 64;
     // per plan, i.e. on the device that is current now (the attribute is per device)
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel<float>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_project_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -427,7 +503,10 @@ int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, 
     g.out_f64 = out_dtype == RTS_F64;
     const int groups = (n_frames + kChromaFR - 1) / kChromaFR;
     const int grid = groups < 1024 ? groups : 1024;
-    hipLaunchKernelGGL(chroma_frames_kernel, dim3(grid), dim3(kChromaNT), h->smem_frames, (hipStream_t)stream, g);
+    if (g.samples_f64)
+        hipLaunchKernelGGL(chroma_frames_kernel<double>, dim3(grid), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(chroma_frames_kernel<float>, dim3(grid), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -463,7 +542,10 @@ int rts_chroma_frames_batch(rts_chroma *h, const void *samples_dev, int sample_d
     g.out_frames_stride = n_frames_max;
     const int groups_b = (n_frames_max + kChromaFR - 1) / kChromaFR;
     const int gx = groups_b < 64 ? groups_b : 64;
-    hipLaunchKernelGGL(chroma_frames_kernel, dim3(gx, B), dim3(kChromaNT), h->smem_frames, (hipStream_t)stream, g);
+    if (g.samples_f64)
+        hipLaunchKernelGGL(chroma_frames_kernel<double>, dim3(gx, B), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(chroma_frames_kernel<float>, dim3(gx, B), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -491,6 +573,12 @@ int rts_chroma_project(rts_chroma *h, const double *spec_dev, int n_frames, int 
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
+
+#ifdef RTS_CHROMA_STAMPS
+int rts_chroma_read_stamps(long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rts::g_chroma_stamps), sizeof(long long) * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int rts_chroma_diff(const void *chroma_dev, int dtype, int n_frames, void *out_dev, void *stream) {
     using namespace rts;
