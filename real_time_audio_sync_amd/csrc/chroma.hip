@@ -40,6 +40,7 @@ struct ChromaArgs {
     const double *window;    // [L]
     const double2 *twiddle;  // [L/2]  exp(-2 pi i n / L)
     const double *fb;        // [12][L/2+1]
+    const double *fbt;       // [L/2+1][12]: the same, bin-major (a thread's 12 weights of one bin are 96 contiguous bytes)
     void *chroma_out;        // [n_frames][12]
     double2 *stft_out;       // [n_frames][L/2+1] or NULL
     const double *spec_in;   // projection-only entry: [n_frames][L/2+1]
@@ -72,28 +73,57 @@ __device__ long long g_chroma_stamps[8];
     } while (0)
 #endif
 
+// Sum over each row of 16 consecutive lanes, left in the row's last lane (row_shr 1, 2, 4, 8 with zero fill).
+__device__ __forceinline__ double row_sum16(double v) {
+#define RTS_ROW_STEP(CTRL)                                                                                     \
+    do {                                                                                                       \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);                \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);                \
+        v = v + __hiloint2double(hi, lo);                                                                      \
+    } while (0)
+    RTS_ROW_STEP(0x111);
+    RTS_ROW_STEP(0x112);
+    RTS_ROW_STEP(0x114);
+    RTS_ROW_STEP(0x118);
+#undef RTS_ROW_STEP
+    return v;
+}
+
 // Steps 4-5 for up to kProjMax frames whose power spectra sit in LDS: frames f = f_first + i * f_step (i < kProjMax)
 // with f < nf, spectrum at spec + f * spec_stride, output frame frame0 + f.  One team of 256 threads (`tid` is the
 // index within the team; `bar` synchronises at least the team): each thread owns bins k = tid (mod 256) and keeps 12
 // running sums per frame, so the 197 KB filterbank is read from L2 once per call.  The 12 x 256 partial sums of a
-// frame are then reduced through LDS (`red`: [12][256] + 192 doubles): 192 threads add 16 each, 12 threads add the 16
-// partials in index order -- a fixed summation order, independent of how many frames share the pass.
-// Every thread executes every barrier, whatever nf is.
+// frame are then reduced in a fixed order, independent of how many frames share the pass (`red`: kProjMax * 192
+// doubles of LDS scratch).  Every thread executes every barrier, whatever nf is.
 template <int kProjMax, class Barrier>
 __device__ __forceinline__ void project_normalize(const ChromaArgs &g, const double *spec, int spec_stride,
                                                   double *red, int frame0, int nf, int f_first, int f_step, int tid,
                                                   Barrier bar) {
     const int nb = g.L / 2 + 1;
+#ifdef RTS_CHROMA_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_chroma_stamps[7] = (long long)__builtin_amdgcn_s_memtime();
+#endif
     double acc[kProjMax][kCh];
 #pragma unroll
     for (int i = 0; i < kProjMax; i++)
 #pragma unroll
         for (int p = 0; p < kCh; p++) acc[i][p] = 0.0;
     if (f_first < nf) {
-        for (int k = tid; k < nb; k += kChromaNT) {
-            double w[kCh];
+        // the 12 weights of the thread's next bin are fetched (L2) while the current bin is accumulated: two register
+        // sets that swap roles by name (a copy would have to wait for the load it copies)
+        double wa[kCh], wb[kCh];
+        auto load_w = [&](double (&w)[kCh], int k) {
+            const int kc = k < nb ? k : nb - 1;
+            const double2 *src = reinterpret_cast<const double2 *>(g.fbt) + (size_t)kc * (kCh / 2);
 #pragma unroll
-            for (int p = 0; p < kCh; p++) w[p] = g.fb[(size_t)p * nb + k];
+            for (int p = 0; p < kCh / 2; p++) {
+                const double2 t = src[p];
+                w[2 * p] = t.x;
+                w[2 * p + 1] = t.y;
+            }
+        };
+        auto accumulate = [&](const double (&w)[kCh], int k) {
+            if (k >= nb) return;
 #pragma unroll
             for (int i = 0; i < kProjMax; i++) {
                 const int f = f_first + i * f_step;
@@ -103,51 +133,60 @@ __device__ __forceinline__ void project_normalize(const ChromaArgs &g, const dou
                     for (int p = 0; p < kCh; p++) acc[i][p] = fma(w[p], sv, acc[i][p]);
                 }
             }
+        };
+        load_w(wa, tid);
+        for (int k = tid; k < nb; k += 2 * kChromaNT) {
+            load_w(wb, k + kChromaNT);
+            accumulate(wa, k);
+            load_w(wa, k + 2 * kChromaNT);
+            accumulate(wb, k + kChromaNT);
         }
     }
+#ifdef RTS_CHROMA_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_chroma_stamps[6] += (long long)__builtin_amdgcn_s_memtime() - g_chroma_stamps[7];
+#endif
+    // Reduction of the 256 partial sums of every (frame, pitch class): 16 consecutive threads by a DPP row reduction
+    // (no LDS, no barrier), the 16 row totals through LDS in index order.  All frames of the pass share the two barriers.
+    double *part = red;  // [kProjMax][12][16] row totals
 #pragma unroll
     for (int i = 0; i < kProjMax; i++) {
-        const int f = f_first + i * f_step;
-        const bool live = f < nf;
-        if (live) {
 #pragma unroll
-            for (int p = 0; p < kCh; p++) red[p * kChromaNT + tid] = acc[i][p];
+        for (int p = 0; p < kCh; p++) {
+            const double t = row_sum16(acc[i][p]);
+            if ((tid & 15) == 15) part[(i * kCh + p) * 16 + (tid >> 4)] = t;
         }
-        bar();
-        if (live && tid < kCh * 16) {
-            const int p = tid >> 4, q = tid & 15;
-            double sum = 0.0;
+    }
+    bar();
+    if (tid < 64) {  // one wave: lane i*12 + p finishes (frame i, pitch class p); then the norms
+        double cp = 0.0;
+        if (tid < kProjMax * kCh) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) sum = sum + red[p * kChromaNT + q * 16 + j];
-            red[kCh * kChromaNT + tid] = sum;
+            for (int q = 0; q < 16; q++) cp = cp + part[tid * 16 + q];
         }
-        bar();
-        if (live && tid < 64) {  // one wave: lane p < 12 finishes bin p, then every lane forms the norm
-            double cp = 0.0;
-            if (tid < kCh) {
 #pragma unroll
-                for (int q = 0; q < 16; q++) cp = cp + red[kCh * kChromaNT + tid * 16 + q];
-            }
+        for (int i = 0; i < kProjMax; i++) {
+            const int f = f_first + i * f_step;
             double ss = 0.0;
 #pragma unroll
             for (int p = 0; p < kCh; p++) {
-                const double c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cp), p),
-                                                  __builtin_amdgcn_readlane(__double2loint(cp), p));
+                const double c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cp), i * kCh + p),
+                                                  __builtin_amdgcn_readlane(__double2loint(cp), i * kCh + p));
                 const double sq = c * c;
                 ss = ss + sq;
             }
             double len = sqrt(ss);
             if (!g.normalize || len < 2.2250738585072014e-308) len = 1.0;  // librosa.util.normalize, fill=None
-            if (tid < kCh) {
+            if (f < nf && tid >= i * kCh && tid < (i + 1) * kCh) {
                 const double v = cp / len;
+                const size_t o = (size_t)(frame0 + f) * kCh + (tid - i * kCh);
                 if (g.out_f64)
-                    reinterpret_cast<double *>(g.chroma_out)[(size_t)(frame0 + f) * kCh + tid] = v;
+                    reinterpret_cast<double *>(g.chroma_out)[o] = v;
                 else
-                    reinterpret_cast<float *>(g.chroma_out)[(size_t)(frame0 + f) * kCh + tid] = (float)v;
+                    reinterpret_cast<float *>(g.chroma_out)[o] = (float)v;
             }
         }
-        bar();
     }
+    bar();
 }
 
 // Two teams of 256 threads per workgroup, each transforming its own frame (two waves per SIMD: the FFT is a chain of
@@ -354,6 +393,222 @@ __global__ void __launch_bounds__(kChromaWG) chroma_frames_kernel(ChromaArgs g) 
 #endif
 }
 
+// ---- fft_len = 4096 (the reference's only setting, chroma.py:20 / wtw.py:27): a specialised kernel -----------------
+// Same structure as above (two teams, one frame each; four frames per pass over the filterbank) with the FFT as four
+// register passes -- radix 8, 8, 8, 4 over the 2048 packed complex points, one butterfly per thread and pass (two in the
+// last) -- instead of eleven radix-2-equivalent levels in six LDS round trips: half the LDS traffic, 8 barriers instead
+// of 12.  The work buffer is padded by one 16-byte slot per 8 so that every pass reads and writes without bank
+// conflicts, samples are indexed with 32-bit arithmetic, and all compile-time strides fold into immediates.
+namespace c4k {
+constexpr int L = 4096, N2 = 2048, NQ = 1024;        // real length, packed complex length, quarter-circle table
+constexpr int ZSLOTS = N2 + N2 / 8;                  // padded work buffer (double2 slots)
+constexpr int SSTRIDE = N2 + 2;
+__device__ __forceinline__ constexpr int zi(int n) { return n + (n >> 3); }
+
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }  // * (-i)
+
+// exp(-2 pi i t / 4096), 0 <= t < 4096, from the quarter table (t < 1024): every quarter turn multiplies by -i
+__device__ __forceinline__ double2 twf(const double2 *twq, int t) {
+    const double2 w = twq[t & (NQ - 1)];
+    const int qd = (t >> 10) & 3;
+    const double2 r1 = (qd & 1) ? make_double2(w.y, -w.x) : w;
+    return (qd & 2) ? make_double2(-r1.x, -r1.y) : r1;
+}
+
+// 8-point DFT of u[0..7] in place (decimation in frequency, outputs in natural order in y)
+__device__ __forceinline__ void dft8(const double2 (&u)[8], double2 (&y)[8]) {
+    const double s = 0.70710678118654752440;
+    const double2 a0 = cadd(u[0], u[4]), a1 = cadd(u[1], u[5]), a2 = cadd(u[2], u[6]), a3 = cadd(u[3], u[7]);
+    const double2 b0 = csub(u[0], u[4]), d1 = csub(u[1], u[5]), d2 = csub(u[2], u[6]), d3 = csub(u[3], u[7]);
+    const double2 b1 = make_double2(s * (d1.x + d1.y), s * (d1.y - d1.x));   // * W8
+    const double2 b2 = mul_mi(d2);                                           // * W8^2 = -i
+    const double2 b3 = make_double2(s * (d3.y - d3.x), -s * (d3.x + d3.y));  // * W8^3
+    {
+        const double2 t0 = cadd(a0, a2), t1 = cadd(a1, a3), t2 = csub(a0, a2), t3 = mul_mi(csub(a1, a3));
+        y[0] = cadd(t0, t1);
+        y[2] = cadd(t2, t3);
+        y[4] = csub(t0, t1);
+        y[6] = csub(t2, t3);
+    }
+    {
+        const double2 t0 = cadd(b0, b2), t1 = cadd(b1, b3), t2 = csub(b0, b2), t3 = mul_mi(csub(b1, b3));
+        y[1] = cadd(t0, t1);
+        y[3] = cadd(t2, t3);
+        y[5] = csub(t0, t1);
+        y[7] = csub(t2, t3);
+    }
+}
+
+// One radix-8 Stockham pass with sub-transform length P (1, 8 or 64): butterfly i = tid reads z[i + 256 m],
+// multiplies input m by exp(-2 pi i k m / (8 P)), k = i mod P, and writes to (i - k) * 8 + k + m * P.
+template <int P, class Bar>
+__device__ __forceinline__ void pass8(double2 *z, const double2 *twq, int tid, Bar bar) {
+    double2 u[8], y[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) u[m] = z[zi(tid + 256 * m)];
+    const int k = tid & (P - 1);
+    if (P > 1) {
+        const int t1 = k * (L / (8 * P));  // < 512
+#pragma unroll
+        for (int m = 1; m < 8; m++) u[m] = cmul(twf(twq, t1 * m), u[m]);
+    }
+    dft8(u, y);
+    bar();
+    const int jj = ((tid - k) << 3) + k;
+#pragma unroll
+    for (int m = 0; m < 8; m++) z[zi(jj + m * P)] = y[m];
+    bar();
+}
+}  // namespace c4k
+
+template <typename ST>
+__global__ void __launch_bounds__(kChromaWG) chroma_frames4096_kernel(ChromaArgs g) {
+    using namespace c4k;
+    extern __shared__ __align__(16) unsigned char ch_smem[];
+    const int team = threadIdx.x >> 8, tid = threadIdx.x & (kChromaNT - 1);
+    double2 *zbase = reinterpret_cast<double2 *>(ch_smem);       // [2][ZSLOTS]
+    double2 *z = zbase + (size_t)team * ZSLOTS;
+    double2 *twq = zbase + 2 * (size_t)ZSLOTS;                   // [NQ]
+    double *spec = reinterpret_cast<double *>(twq + NQ);         // [kChromaFR][SSTRIDE]
+    double *red = reinterpret_cast<double *>(z);                 // the team's reduction scratch (26 KB of its 36 KB)
+    auto bar = [] { lds_barrier(); };
+
+    for (int n = threadIdx.x; n < NQ; n += kChromaWG) twq[n] = g.twiddle[n];
+    __syncthreads();
+
+    const int sb = blockIdx.y;  // batched launch: this workgroup's stream
+    if (g.n_frames_b) {
+        g.n_frames = g.n_frames_b[sb];
+        g.n_samples = g.n_samples_b[sb];
+        g.samples = reinterpret_cast<const ST *>(g.samples) + (long long)sb * g.sample_stride;
+        const long long oo = (long long)sb * g.out_frames_stride * kCh;
+        g.chroma_out = g.out_f64 ? (void *)(reinterpret_cast<double *>(g.chroma_out) + oo)
+                                 : (void *)(reinterpret_cast<float *>(g.chroma_out) + oo);
+    }
+    const ST *samples = reinterpret_cast<const ST *>(g.samples);
+    const int n_samples = (int)g.n_samples;  // the host routes longer signals to the generic kernel
+    const int off0 = (int)g.frame_offset, hop = g.hop;
+
+    constexpr int kPairs = N2 / kChromaNT;  // 8 sample pairs per thread: n = tid + 256 r -> x[2n], x[2n+1]
+    double win_re[kPairs], win_im[kPairs];
+#pragma unroll
+    for (int r = 0; r < kPairs; r++) {
+        const int n = tid + r * kChromaNT;
+        win_re[r] = g.window[2 * n];
+        win_im[r] = g.window[2 * n + 1];
+    }
+    // the team's next frame, fetched one frame ahead and left untouched until it is used (a use would wait for the load);
+    // indices clamped into the buffer, out-of-range positions zeroed at use
+    ST ps0[kPairs], ps1[kPairs];
+#pragma unroll
+    for (int r = 0; r < kPairs; r++) ps0[r] = ps1[r] = (ST)0;
+    const int hi = n_samples > 0 ? n_samples - 1 : 0;
+    auto fetch_frame = [&](int frame) {
+        const int s0 = (frame < g.n_frames) ? off0 + frame * hop : 0;
+#pragma unroll
+        for (int r = 0; r < kPairs; r++) {
+            const int i0 = s0 + 2 * (tid + r * kChromaNT), i1 = i0 + 1;
+            ps0[r] = samples[i0 < 0 ? 0 : (i0 > hi ? hi : i0)];
+            ps1[r] = samples[i1 < 0 ? 0 : (i1 > hi ? hi : i1)];
+        }
+    };
+    fetch_frame(blockIdx.x * kChromaFR + team);
+#ifdef RTS_CHROMA_STAMPS
+    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long last_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    for (int frame0 = blockIdx.x * kChromaFR; frame0 < g.n_frames; frame0 += gridDim.x * kChromaFR) {
+        const int nf = (g.n_frames - frame0 < kChromaFR) ? g.n_frames - frame0 : kChromaFR;
+        for (int round = 0; round < kChromaFR / 2; round++) {
+            const int f = 2 * round + team;
+            const int frame = frame0 + f;
+            const bool live = f < nf;
+            CH_STAMP(0);
+            // 1. window, pack as complex
+            const int s0 = off0 + frame * hop;
+#pragma unroll
+            for (int r = 0; r < kPairs; r++) {
+                const int n = tid + r * kChromaNT;
+                const int i0 = s0 + 2 * n;
+                const double x0 = (i0 >= 0 && i0 < n_samples) ? (double)ps0[r] : 0.0;
+                const double x1 = (i0 + 1 >= 0 && i0 + 1 < n_samples) ? (double)ps1[r] : 0.0;
+                z[zi(n)] = make_double2(x0 * win_re[r], x1 * win_im[r]);
+            }
+            {
+                const long long nxt = round + 1 < kChromaFR / 2 ? (long long)frame + 2
+                                                                : (long long)frame0 + (long long)gridDim.x * kChromaFR + team;
+                fetch_frame(nxt < g.n_frames ? (int)nxt : g.n_frames);
+            }
+            bar();
+            CH_STAMP(1);
+            // 2. 2048-point complex FFT: radix 8, 8, 8, then 4
+            pass8<1>(z, twq, tid, bar);
+            pass8<8>(z, twq, tid, bar);
+            pass8<64>(z, twq, tid, bar);
+            {
+                constexpr int P = 512, Q = N2 / 4;
+                double2 o[2][4];
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int i = tid + r * kChromaNT;  // k = i (P = 512 = N2/4)
+                    const double2 u0 = z[zi(i)];
+                    const double2 u1 = cmul(twf(twq, 2 * i), z[zi(i + Q)]);
+                    const double2 u2 = cmul(twf(twq, 4 * i), z[zi(i + 2 * Q)]);
+                    const double2 u3 = cmul(twf(twq, 6 * i), z[zi(i + 3 * Q)]);
+                    const double2 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = mul_mi(csub(u1, u3));
+                    o[r][0] = cadd(a0, a2);
+                    o[r][1] = cadd(a1, a3);
+                    o[r][2] = csub(a0, a2);
+                    o[r][3] = csub(a1, a3);
+                }
+                bar();
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int i = tid + r * kChromaNT;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) z[zi(i + m * P)] = o[r][m];
+                }
+                bar();
+            }
+            CH_STAMP(2);
+            // 3. untangle: X[k] = E[k] + W_L^k O[k], E = (Z[k] + conj Z[N2-k]) / 2, O = (Z[k] - conj Z[N2-k]) / (2i)
+            constexpr int nb = N2 + 1;
+            double *sp = spec + (size_t)f * SSTRIDE;
+            if (live) {
+                // bins k and N2 - k share their two inputs: X[N2 - k] = conj(E[k] - W_L^k O[k])
+                for (int k = tid; k <= N2 / 2; k += kChromaNT) {
+                    const double2 a = z[zi(k)];
+                    const double2 bq = z[zi((N2 - k) & (N2 - 1))];  // Z[N2] == Z[0]
+                    const double2 b = make_double2(bq.x, -bq.y);     // conj
+                    const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+                    const double2 dm = csub(a, b);
+                    const double2 o = make_double2(0.5 * dm.y, -0.5 * dm.x);  // dm / (2i)
+                    const double2 wo = cmul(twf(twq, k), o);
+                    const double2 x = cadd(e, wo);
+                    const double2 d = csub(e, wo);
+                    const double2 x2 = make_double2(d.x, -d.y);
+                    sp[k] = x.x * x.x + x.y * x.y;
+                    if (g.stft_out) g.stft_out[(size_t)frame * nb + k] = x;
+                    if (k != N2 - k) {
+                        sp[N2 - k] = x2.x * x2.x + x2.y * x2.y;
+                        if (g.stft_out) g.stft_out[(size_t)frame * nb + (N2 - k)] = x2;
+                    }
+                }
+            }
+            bar();
+            CH_STAMP(3);
+        }
+        if (g.chroma_out) project_normalize<kChromaFR / 2>(g, spec, SSTRIDE, red, frame0, nf, team, 2, tid, bar);
+        CH_STAMP(4);
+    }
+#ifdef RTS_CHROMA_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 6; i++) g_chroma_stamps[i] = st_[i];
+#endif
+}
+
 __global__ void __launch_bounds__(kChromaNT) chroma_project_kernel(ChromaArgs g) {
     extern __shared__ __align__(16) unsigned char ch_smem[];
     const int nb = g.L / 2 + 1;
@@ -392,8 +647,19 @@ struct rts_chroma {
     double *window;    // device [L]
     double2 *twiddle;  // device [L/2]
     double *fb;        // device [12][L/2+1]
-    size_t smem_frames, smem_project;
+    double *fbt;       // device [L/2+1][12]
+    size_t smem_frames, smem_frames4096, smem_project;
 };
+
+static hipError_t upload_transposed(double *dst_dev, const double *fb_host, int nb) {
+    double *t = (double *)malloc(sizeof(double) * rts::kCh * nb);
+    if (!t) return hipErrorOutOfMemory;
+    for (int k = 0; k < nb; k++)
+        for (int p = 0; p < rts::kCh; p++) t[(size_t)k * rts::kCh + p] = fb_host[(size_t)p * nb + k];
+    const hipError_t e = hipMemcpy(dst_dev, t, sizeof(double) * rts::kCh * nb, hipMemcpyHostToDevice);
+    free(t);
+    return e;
+}
 
 extern "C" {
 
@@ -434,7 +700,9 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
         (e = hipMalloc((void **)&h->fb, sizeof(double) * kCh * nb)) != hipSuccess ||
         (e = hipMemcpy(h->window, win, sizeof(double) * L, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(h->twiddle, tw, sizeof(double2) * N2, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(h->fb, fb_host, sizeof(double) * kCh * nb, hipMemcpyHostToDevice)) != hipSuccess) {
+        (e = hipMemcpy(h->fb, fb_host, sizeof(double) * kCh * nb, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMalloc((void **)&h->fbt, sizeof(double) * kCh * nb)) != hipSuccess ||
+        (e = upload_transposed(h->fbt, fb_host, nb)) != hipSuccess) {
         free(win);
         free(tw);
         rts_chroma_destroy(h);
@@ -446,7 +714,14 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
                      ((2 * N2 >= 3264) ? 0 : sizeof(double) * 2 * 3264) + 64;
     h->smem_project = sizeof(double) * ((size_t)kChromaFR * (nb + 1) + 3264) + 64;
     // per plan, i.e. on the device that is current now (the attribute is per device)
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel<float>),
+    h->smem_frames4096 = sizeof(double2) * (2 * (size_t)c4k::ZSLOTS + c4k::NQ) + sizeof(double) * (size_t)kChromaFR * c4k::SSTRIDE + 64;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames4096_kernel<float>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames4096_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel<float>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel<double>),
@@ -467,6 +742,7 @@ int rts_chroma_destroy(rts_chroma *h) {
     if (h->window) (void)hipFree(h->window);
     if (h->twiddle) (void)hipFree(h->twiddle);
     if (h->fb) (void)hipFree(h->fb);
+    if (h->fbt) (void)hipFree(h->fbt);
     free(h);
     return RTS_OK;
 }
@@ -491,6 +767,7 @@ int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, 
     g.window = h->window;
     g.twiddle = h->twiddle;
     g.fb = h->fb;
+    g.fbt = h->fbt;
     g.chroma_out = chroma_out_dev;
     g.stft_out = reinterpret_cast<double2 *>(stft_out_dev);
     g.n_samples = n_samples;
@@ -503,10 +780,18 @@ int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, 
     g.out_f64 = out_dtype == RTS_F64;
     const int groups = (n_frames + kChromaFR - 1) / kChromaFR;
     const int grid = groups < 1024 ? groups : 1024;
-    if (g.samples_f64)
+    // fft_len 4096 with 32-bit sample indices: the specialised kernel; anything else: the generic one
+    const bool fast = (h->L == 4096) && (n_samples + 2LL * h->L + (long long)n_frames * h->hop < 0x7fffffffLL);
+    if (fast) {
+        if (g.samples_f64)
+            hipLaunchKernelGGL(chroma_frames4096_kernel<double>, dim3(grid), dim3(kChromaWG), h->smem_frames4096, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL(chroma_frames4096_kernel<float>, dim3(grid), dim3(kChromaWG), h->smem_frames4096, (hipStream_t)stream, g);
+    } else if (g.samples_f64) {
         hipLaunchKernelGGL(chroma_frames_kernel<double>, dim3(grid), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
-    else
+    } else {
         hipLaunchKernelGGL(chroma_frames_kernel<float>, dim3(grid), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
+    }
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -529,6 +814,7 @@ int rts_chroma_frames_batch(rts_chroma *h, const void *samples_dev, int sample_d
     g.window = h->window;
     g.twiddle = h->twiddle;
     g.fb = h->fb;
+    g.fbt = h->fbt;
     g.chroma_out = chroma_out_dev;
     g.frame_offset = -(long long)pad_left;
     g.L = h->L;
@@ -542,10 +828,17 @@ int rts_chroma_frames_batch(rts_chroma *h, const void *samples_dev, int sample_d
     g.out_frames_stride = n_frames_max;
     const int groups_b = (n_frames_max + kChromaFR - 1) / kChromaFR;
     const int gx = groups_b < 64 ? groups_b : 64;
-    if (g.samples_f64)
+    const bool fast = (h->L == 4096) && (sample_stride + 2LL * h->L + (long long)n_frames_max * h->hop < 0x7fffffffLL);
+    if (fast) {
+        if (g.samples_f64)
+            hipLaunchKernelGGL(chroma_frames4096_kernel<double>, dim3(gx, B), dim3(kChromaWG), h->smem_frames4096, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL(chroma_frames4096_kernel<float>, dim3(gx, B), dim3(kChromaWG), h->smem_frames4096, (hipStream_t)stream, g);
+    } else if (g.samples_f64) {
         hipLaunchKernelGGL(chroma_frames_kernel<double>, dim3(gx, B), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
-    else
+    } else {
         hipLaunchKernelGGL(chroma_frames_kernel<float>, dim3(gx, B), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
+    }
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -561,6 +854,7 @@ int rts_chroma_project(rts_chroma *h, const double *spec_dev, int n_frames, int 
     ChromaArgs g;
     memset(&g, 0, sizeof(g));
     g.fb = h->fb;
+    g.fbt = h->fbt;
     g.spec_in = spec_dev;
     g.chroma_out = chroma_out_dev;
     g.L = h->L;
