@@ -2,7 +2,8 @@
 """Timings of the strip-DP kernels (csrc/sdp.h): offline DTW and windowed time warping on synthetic chroma.
 Device time from HIP events on the launch stream.  One JSON object per line.
 
-    python tools/bench_sdp.py [dtw] [wtw] [big]      (default: dtw wtw; `big` adds the 19 380^2 DTW)
+    python tools/bench_sdp.py [dtw] [wtw] [big] [chroma] [wtw10k]
+    (default: dtw wtw; `big` adds the 19 380^2 DTW, `chroma` 30 minutes of audio, `wtw10k` only the W = 10 000 stream)
 """
 import json
 import os
@@ -36,10 +37,10 @@ def main():
     from real_time_audio_sync_amd.otw_batch import frames_tensor
     what = set(sys.argv[1:]) or {"dtw", "wtw"}
     dev = torch.device("cuda:0")
-    waves = os.environ.get("RTS_SDP_WAVES", "default")
+    cfg = os.environ.get("RTS_SDP_CONFIG", "default")
 
     def emit(**kw):
-        kw["sdp_waves"] = waves
+        kw["sdp_config"] = cfg
         print(json.dumps(kw), flush=True)
 
     if "dtw" in what:
@@ -66,7 +67,15 @@ def main():
         emit(kernel="rts_dtw", M=int(a.shape[0]), N=int(b.shape[0]), pairs=1, seconds=t, cells_per_s=cells / t,
              algorithmic_bytes=cells * 16.25, hbm_GBps=cells * 16.25 / t / 1e9,
              note="8 B cost + 8 B acc written, 2 bits of step code per cell")
-    if "wtw" in what:
+    if "chroma" in what:
+        from real_time_audio_sync_amd import chroma
+        plan = chroma.ChromaPlan(4096, 2048, 22050)
+        wav = torch.from_numpy((np.random.RandomState(0).rand(30 * 60 * 22050) - 0.5).astype(np.float32)).to(dev)
+        m = plan.num_frames(wav.numel(), 2048)
+        t = timed(lambda: plan.frames(wav, pad_left=2048))
+        emit(kernel="chroma_frames4096_kernel", frames=m, seconds=t, frames_per_s=m / t,
+             algorithmic_bytes=m * (2048 * 4 + 96), hbm_GBps=m * (2048 * 4 + 96) / t / 1e9)
+    if "wtw" in what or "wtw10k" in what:
         ref5 = synth.synth_ref(19380, seed=500)
         live5 = synth.synth_live(ref5, seed=501)
         eng5 = wtw.BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref5.T)).to(dev), 10000, 5000, 1)
@@ -77,12 +86,13 @@ def main():
             eng5.push(c5, precheck=True)
         t = timed(run5, reps=3, warm=1)
         s5 = eng5.state()
-        emit(kernel="rts_wtw_push (W=10000: wtw_big_dp_kernel + wtw_big_ctl_kernel per window)", streams=1, W=10000,
+        emit(kernel="rts_wtw_push (W=10000: dp + hops + 2 segment passes + ctl per window)", streams=1, W=10000,
              hop=5000, windows=s5["windows"], seconds=t, seconds_per_window=t / max(1, s5["windows"]),
              cells_per_s=s5["cells"] / t, frames_per_s=s5["chroma_ptr"] / t,
              algorithmic_bytes_per_window=2 * 10000 * 10000 + 2 * 12 * 4 * 10000,
              roofline_GBps=(2 * 10000 * 10000 + 2 * 12 * 4 * 10000) * s5["windows"] / t / 1e9)
         eng5.close()
+    if "wtw" in what:
         for W, hop, B, nref in ((700, 350, 8, 2500), (2000, 1000, 4, 5000)):
             ref, lives = synth.synth_batch(nref, B, seed=90 + W)
             eng = wtw.BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev), W, hop, B)
@@ -119,7 +129,7 @@ def main():
         st = eng.states()
         frames = int(st[:, 0].sum())
         cells = int(sum((int(np.uint32(s[7])) << 32) | int(np.uint32(s[6])) for s in st))
-        emit(kernel="rts_wtw_push (wtw_advance_kernel)", streams=64, W=100, hop=50, frames=frames,
+        emit(kernel="rts_wtw_push (W=100: strip-DP path)", streams=64, W=100, hop=50, frames=frames,
              windows=int(st[:, 5].sum()), seconds=t, frames_per_s=frames / t, cells_per_s=cells / t)
 
 

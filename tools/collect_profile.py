@@ -66,8 +66,9 @@ def main():
     print("bench: %.3f ms/step, %.3e frames/s" % (final["ms_per_step"], final["value"]), flush=True)
 
     d = os.path.join(out, "trace")
+    # --no-cpu: the CPU legs fork worker processes, which must not happen under the profiler's preloaded runtime
     under = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--",
-                 "python3", "bench.py", "--steps", "20", "--warmup", "3"],
+                 "python3", "bench.py", "--steps", "20", "--warmup", "3", "--no-cpu"],
                 os.path.join(out, tag + "_bench_under_rocprof.json"))
     stats = find(d, "kernel_stats.csv")
     with open(stats) as f, open(os.path.join(out, tag + "_otw_kernel_stats.csv"), "w") as g:
@@ -103,6 +104,51 @@ def main():
     with open(os.path.join(out, "otw_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     print(json.dumps(summary["pmc_mean_per_dispatch"], indent=1))
+    secondary(tag, out)
+
+
+def kernel_rows(stats_csv, names):
+    with open(stats_csv) as f:
+        return [r for r in csv.DictReader(f) if any(n in r["Name"] for n in names)]
+
+
+def secondary(tag, out):
+    """Strip-DP (DTW / WTW) and chroma kernels: rocprofv3 kernel statistics of tools/bench_sdp.py and of a chroma run,
+    and the HBM counters of the W = 10 000 window kernel."""
+    d = os.path.join(out, "trace_sdp")
+    p = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--",
+                        "python3", "tools/bench_sdp.py", "dtw", "wtw", "big", "chroma"], cwd=ROOT,
+                       env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    if p.returncode != 0:
+        sys.stderr.write(p.stderr[-3000:])
+        raise SystemExit("bench_sdp under rocprofv3 failed")
+    with open(os.path.join(out, tag + "_sdp_under_rocprof.jsonl"), "w") as f:
+        f.write("".join(l + "\n" for l in p.stdout.splitlines() if l.startswith("{")))
+    stats = find(d, "kernel_stats.csv")
+    keep = ("sdp_kernel", "big_dp", "big_ctl", "big_hops", "big_segment", "dtw_hops", "dtw_segment", "dtw_cost", "dtw_prep",
+            "chroma_frames", "wtw_advance")
+    with open(stats) as f, open(os.path.join(out, tag + "_sdp_kernel_stats.csv"), "w") as g:
+        for i, line in enumerate(f):
+            if i == 0 or any(k in line for k in keep):
+                g.write(line[:400] + ("\n" if len(line) > 400 else ""))
+    # the W = 10 000 window: HBM counters of wtw_big_dp_kernel, separate passes
+    pmc = {}
+    for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+        dd = os.path.join(out, "pmc_sdp_" + name)
+        run(["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", dd, "--",
+             "python3", "tools/bench_sdp.py", "wtw10k"])
+        vals = []
+        with open(find(dd, "counter_collection.csv")) as f:
+            for row in csv.DictReader(f):
+                if "wtw_big_dp_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counters[0]:
+                    vals.append(float(row["Counter_Value"]))
+        vals = [v for v in vals if v > 0.5 * max(vals)] if vals else []  # rounds with a pending window
+        pmc[counters[0]] = sum(vals) / max(len(vals), 1)
+        pmc[counters[0] + "_dispatches"] = len(vals)
+    with open(os.path.join(out, tag + "_sdp_pmc.json"), "w") as f:
+        json.dump({"kernel": "wtw_big_dp_kernel (W = 10 000, one window per dispatch)", "KB_per_dispatch": pmc,
+                   "hbm_bytes_per_window": int((2 * pmc.get("FETCH_SIZE", 0) + pmc.get("WRITE_SIZE", 0)) * 1024),
+                   "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md"}, f, indent=1)
 
 
 if __name__ == "__main__":
