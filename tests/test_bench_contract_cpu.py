@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01l_bench_final.json, produced by `python bench.py` on an MI355X)
+"""The committed bench line (profiles/r02a_bench_final.json, produced by `python bench.py` on an MI355X)
 carries every field the driver's contract asks for, and its numbers are self-consistent."""
 import json
 import os
@@ -7,7 +7,7 @@ from conftest import ROOT
 
 
 def test_bench_line_contract():
-    r = json.load(open(os.path.join(ROOT, "profiles", "r01l_bench_final.json")))
+    r = json.load(open(os.path.join(ROOT, "profiles", "r02a_bench_final.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert r["metric"] == base["metric"] and r["unit"] == "frames/s"
     for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -15,7 +15,7 @@ def test_bench_line_contract():
         assert key in r, key
     assert r["n_gpus"] == 1 and r["higher_is_better"] is True and r["scaling"] == "weak"
     assert r["vs_baseline"] is None            # BASELINE.md publishes no number for this metric
-    assert r["dtype"] == "f64" and r["data"] == "synthetic" and "workload" in r["config"]
+    assert r["dtype"].startswith("f64") and r["data"] == "synthetic" and "workload" in r["config"]
     assert "model" not in r["config"]
     # value = frames of one step / time per step
     assert abs(r["value"] - r["config"]["frames_per_step"] / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
@@ -25,6 +25,13 @@ def test_bench_line_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
     assert rf["traffic"] is None or rf["traffic"] < rf["algorithmic_bytes_per_launch"]
+    lm = rf["latency_model"]                   # the bound this configuration actually runs against
+    assert abs(lm["cycles_per_step"] - rf["launch_ms"] * 1e-3 * lm["f_clk_hz"] / lm["steps_longest_stream"]) < 1e-6 * lm["cycles_per_step"]
+    assert r["value"] <= lm["bound_frames_per_s"] * 1.02
     cb = r["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["sample"]
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["sample"]
+    legs = cb["legs"]
+    assert legs["c_port_1core"]["cores"] == 1 and legs["numpy_1core"]["cores"] == 1 and legs["numpy_1core"]["path_equals_c_port"]
+    assert cb["cores"] == legs["c_port_allcores"]["cores"] >= 2 and cb["value"] == legs["c_port_allcores"]["value"]
+    assert legs["c_port_allcores"]["value"] > legs["c_port_1core"]["value"] > legs["numpy_1core"]["value"]
     assert r["parity"]["path_mismatches"] == 0 and r["parity"]["streams_checked"] == 64
