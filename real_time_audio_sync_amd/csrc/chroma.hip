@@ -649,7 +649,17 @@ struct rts_chroma {
     double *fb;        // device [12][L/2+1]
     double *fbt;       // device [L/2+1][12]
     size_t smem_frames, smem_frames4096, smem_project;
+    int device;  // the HIP device the plan's tables live on
 };
+
+static int chroma_check_device(const rts_chroma *h) {
+    int d = -1;
+    RTS_HIP(hipGetDevice(&d));
+    if (d != h->device)
+        return rts::set_error(RTS_ERR_INVALID, "plan was created on device %d but device %d is current "
+                                               "(one process per GPU, or hipSetDevice before the call)", h->device, d);
+    return RTS_OK;
+}
 
 static hipError_t upload_transposed(double *dst_dev, const double *fb_host, int nb) {
     double *t = (double *)malloc(sizeof(double) * rts::kCh * nb);
@@ -681,6 +691,10 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
     if (!h) return set_error(RTS_ERR_INVALID, "out of host memory");
     h->L = fft_len;
     h->hop = hop;
+    if (hipGetDevice(&h->device) != hipSuccess) {
+        free(h);
+        return set_error(RTS_ERR_HIP, "hipGetDevice failed");
+    }
     const int L = fft_len, N2 = L / 2, nb = N2 + 1;
     double *win = (double *)malloc(sizeof(double) * L);
     double2 *tw = (double2 *)malloc(sizeof(double2) * N2);
@@ -761,6 +775,7 @@ int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, 
         return set_error(RTS_ERR_INVALID, "n_frames=%d exceeds the %lld full frames in %lld samples", n_frames,
                          rts_chroma_num_frames(n_samples, h->L, h->hop, pad_left), n_samples);
     if (n_frames == 0) return RTS_OK;
+    if (int rc = chroma_check_device(h); rc != RTS_OK) return rc;
     ChromaArgs g;
     memset(&g, 0, sizeof(g));
     g.samples = samples_dev;
@@ -808,6 +823,7 @@ int rts_chroma_frames_batch(rts_chroma *h, const void *samples_dev, int sample_d
         return set_error(RTS_ERR_INVALID, "bad dtype");
     if (B < 1 || n_frames_max < 0 || pad_left < 0 || sample_stride < 0) return set_error(RTS_ERR_INVALID, "bad size");
     if (n_frames_max == 0) return RTS_OK;
+    if (int rc = chroma_check_device(h); rc != RTS_OK) return rc;
     ChromaArgs g;
     memset(&g, 0, sizeof(g));
     g.samples = samples_dev;

@@ -449,6 +449,7 @@ struct rts_wtw {
     uint32_t *codes;
     unsigned long long *bnd;
     int big_waves, big_helpers, n_rg, big_grid, use_big;
+    int device;  // the HIP device the handle's buffers live on
     size_t smem;
 };
 
@@ -470,6 +471,10 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     rts_wtw *h = (rts_wtw *)calloc(1, sizeof(rts_wtw));
     if (!h) return set_error(RTS_ERR_INVALID, "out of host memory");
     h->ref = chroma_ref_dev;
+    if (hipError_t ed = hipGetDevice(&h->device); ed != hipSuccess) {
+        free(h);
+        return set_error(RTS_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(ed));
+    }
     h->M = M;
     h->N = 2 * M;  // wtw.py:52
     h->B = B;
@@ -581,6 +586,13 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     if (n_max < 0) return set_error(RTS_ERR_INVALID, "n_max < 0");
     if (n_max > 0 && !cols_dev) return set_error(RTS_ERR_INVALID, "cols_dev is NULL");
     if (cols_dtype != RTS_F32 && cols_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad cols_dtype %d", cols_dtype);
+    {
+        int d = -1;
+        RTS_HIP(hipGetDevice(&d));
+        if (d != h->device)
+            return set_error(RTS_ERR_INVALID, "handle was created on device %d but device %d is current "
+                                              "(one process per GPU, or hipSetDevice before the call)", h->device, d);
+    }
     hipStream_t s = (hipStream_t)stream;
     if (precheck) {
         hipLaunchKernelGGL(wtw_precheck_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, h->state, h->B, h->M, h->N);

@@ -120,3 +120,31 @@ def test_dtw_long_sequences_hbm_diagonals():
     assert abs(total - float(acc[0, -1, -1])) <= 1e-9 * max(1.0, abs(total))
     # synthetic warps stay within 0.8..1.25 of the diagonal
     assert np.abs(p[:, 1] - p[:, 0] * (n / float(m))).max() < 0.2 * n
+
+
+def test_dtw_batched_pipelines_side_by_side():
+    """Several pairs whose strip pipelines span many workgroups each, in one launch (every pair's row groups hand
+    their bottom rows to the next through HBM while the other pairs' pipelines run beside them), with float64 and
+    float32 inputs and a shared b: every pair's cost, acc_cost, back-pointers and path against the oracle."""
+    import oracle
+    from real_time_audio_sync_amd import synth
+    from real_time_audio_sync_amd.dtw import dtw_batch
+    from real_time_audio_sync_amd.otw_batch import frames_tensor
+    dev = torch.device("cuda:0")
+    ref = synth.synth_ref(333, seed=901)
+    lives = [synth.synth_live(synth.synth_ref(900, seed=910 + k), seed=920 + k, max_frames=700)[:, :700] for k in range(6)]
+    assert all(l.shape[1] == 700 for l in lives)
+    for tdt in (torch.float64, torch.float32):
+        a = torch.stack([frames_tensor(l, dev, tdt) for l in lives])       # [6][700][12]: 11 strips per pair
+        b = frames_tensor(ref, dev, tdt)
+        cost, acc, back, path, plen = dtw_batch(a, b)
+        torch.cuda.synchronize()
+        for k, l in enumerate(lives):
+            lk = l.astype(np.float32).astype(np.float64) if tdt == torch.float32 else l
+            rk = ref.astype(np.float32).astype(np.float64) if tdt == torch.float32 else ref
+            ocost, oacc, opath, oback = oracle.dtw(lk, rk)
+            n = int(plen[k])
+            assert np.array_equal(path[k, :n].cpu().numpy(), opath), (str(tdt), k)
+            assert np.array_equal(acc[k].cpu().numpy(), oacc), (str(tdt), k)
+            assert np.array_equal(cost[k].cpu().numpy(), ocost), (str(tdt), k)
+            assert np.array_equal(back[k].cpu().numpy(), oback), (str(tdt), k)
