@@ -166,6 +166,18 @@ struct DtwPolicy {
         for (int f = 0; f < kF; f++) s = fma(x[f], y[f], s);
         return 1.0 - s;
     }
+    // two columns at once, the two dependent fma chains interleaved (a lone chain is latency-bound)
+    static __device__ __forceinline__ void cost_pair(const double (&x)[kF], double, const double (&ya)[kF], double,
+                                                     const double (&yb)[kF], double, double &ca, double &cb) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int f = 0; f < kF; f++) {
+            sa = fma(x[f], ya[f], sa);
+            sb = fma(x[f], yb[f], sb);
+        }
+        ca = 1.0 - sa;
+        cb = 1.0 - sb;
+    }
     static __device__ __forceinline__ void cell(bool first_row, bool first_col, double up, double left, double diag,
                                                 double c, double &dv, int &code) {
         // value and step code separately: the value is what the next step waits for (two v_min_f64 instead of two
@@ -216,6 +228,23 @@ struct WtwPolicy {
             t2 = t2 + b;
         }
         return 1.0 - (t1 + t2) / (nx * ny);
+    }
+    static __device__ __forceinline__ void cost_pair(const double (&x)[kF], double nx, const double (&ya)[kF], double nya,
+                                                     const double (&yb)[kF], double nyb, double &ca, double &cb) {
+        double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int f = 0; f < kF; f += 4) {
+            const double ma3 = ya[f + 2] * x[f + 2], mb3 = yb[f + 2] * x[f + 2];
+            const double ma4 = ya[f + 3] * x[f + 3], mb4 = yb[f + 3] * x[f + 3];
+            const double pa = fma(ya[f], x[f], ma3), pb = fma(yb[f], x[f], mb3);
+            const double qa = fma(ya[f + 1], x[f + 1], ma4), qb = fma(yb[f + 1], x[f + 1], mb4);
+            a1 = a1 + pa;
+            b1 = b1 + pb;
+            a2 = a2 + qa;
+            b2 = b2 + qb;
+        }
+        ca = 1.0 - (a1 + a2) / (nx * nya);
+        cb = 1.0 - (b1 + b2) / (nx * nyb);
     }
     static __device__ __forceinline__ void cell(bool first_row, bool first_col, double up, double left, double diag,
                                                 double c, double &dv, int &code) {
@@ -274,6 +303,16 @@ __device__ __forceinline__ void prep_column(const void *y, int y_f64, long long 
 __host__ __device__ constexpr bool helper_takes_column(int H, int hidx, int kk, int h0cols) {  // kk: column in the chunk
     if (H == 3) return kk < h0cols ? hidx == 0 : (hidx != 0 && ((kk - h0cols) & 1) == (hidx - 1));
     return hidx == 0 ? (kk % 8) < 3 : (kk % 8) >= 3;  // H == 2: 6 + 10
+}
+__host__ __device__ constexpr int helper_column_ordinal(int H, int hidx, int kk, int h0cols) {  // how many of mine before kk
+    int n = 0;
+    for (int q = 0; q < kk; q++) n += helper_takes_column(H, hidx, q, h0cols) ? 1 : 0;
+    return n;
+}
+__host__ __device__ constexpr int helper_next_column(int H, int hidx, int kk, int h0cols) {  // my next column after kk, or 16
+    for (int q = kk + 1; q < 16; q++)
+        if (helper_takes_column(H, hidx, q, h0cols)) return q;
+    return 16;
 }
 __host__ __device__ constexpr bool helper_takes_rows(int H, int hidx, int it) {  // it: group of 8 tile rows
     if (H == 3) return hidx != 0 && (it & 1) == (hidx - 1);
@@ -367,22 +406,41 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
                     const int c0 = kChunk * mh;
                     const int r0 = (c0 + lane) % kRing;  // ring step of (column c0, my row)
                     const double2 *recs = reinterpret_cast<const double2 *>(yst + (size_t)(mh & 1) * kChunk * kYRec);
-                    static_for<0, kChunk>([&](auto kc) {
-                        constexpr int kk = decltype(kc)::value;  // column within the chunk
-                        if constexpr (helper_takes_column(H, HIDX, kk, P::kHelper0Cols)) {
+                    auto load_rec = [&](int kk, double (&y)[kF], double &ny) {
                         const double2 *rec = recs + (size_t)kk * (kYRec / 2);  // same address in every lane
-                        double y[kF];
 #pragma unroll
                         for (int f = 0; f < kF / 2; f++) {
                             const double2 t = rec[f];
                             y[2 * f] = t.x;
                             y[2 * f + 1] = t.y;
                         }
-                        const double ny = P::kNorm ? rec[kF / 2].x : 0.0;
-                        const double c = P::cost(x, nx, y, ny);
+                        ny = P::kNorm ? rec[kF / 2].x : 0.0;
+                    };
+                    auto put = [&](int kk, double c) {
                         int r = r0 + kk;
                         r = (r >= kRing) ? r - kRing : r;
                         cring[r * 64 + lane] = c;
+                    };
+                    // my columns of the chunk, two at a time (two interleaved dependency chains per lane)
+                    static_for<0, kChunk>([&](auto kc) {
+                        constexpr int kk = decltype(kc)::value;  // column within the chunk
+                        if constexpr (helper_takes_column(H, HIDX, kk, P::kHelper0Cols)) {
+                            constexpr int ord = helper_column_ordinal(H, HIDX, kk, P::kHelper0Cols);
+                            constexpr int nxt = helper_next_column(H, HIDX, kk, P::kHelper0Cols);
+                            if constexpr ((ord & 1) == 0) {
+                                if constexpr (nxt < kChunk) {
+                                    double ya[kF], yb[kF], nya, nyb, ca, cb;
+                                    load_rec(kk, ya, nya);
+                                    load_rec(nxt, yb, nyb);
+                                    P::cost_pair(x, nx, ya, nya, yb, nyb, ca, cb);
+                                    put(kk, ca);
+                                    put(nxt, cb);
+                                } else {
+                                    double y[kF], ny;
+                                    load_rec(kk, y, ny);
+                                    put(kk, P::cost(x, nx, y, ny));
+                                }
+                            }
                         }
                     });
                 }
