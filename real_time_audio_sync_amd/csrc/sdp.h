@@ -382,6 +382,9 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
             dst[lane] = pc0;
             if (lane + 64 < kChunk * 7) dst[lane + 64] = pc1;
         };
+        // output address of (tile row lane >> 3, column pair lane & 7) of row-group it = 0, chunk 0; the element of row r
+        // and step-in-chunk q0 sits at column 16 mf + q0 - r
+        double *drow = STAGE ? pb.D + ((size_t)strip * 64 + (lane >> 3)) * pb.ldD + (2 * (lane & 7) - (lane >> 3)) : nullptr;
         // the helper's role is fixed for the launch: one specialised loop per helper index, no per-column tests
         auto helper_main = [&](auto hic) {
         constexpr int HIDX = decltype(hic)::value;
@@ -465,25 +468,40 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
                             v1[it] = t[(q0 + 1) * kStageLd + r];
                         }
                     });
-                    static_for<0, 8>([&](auto itc) {
-                        constexpr int it = decltype(itc)::value;
-                        if constexpr (helper_takes_rows(H, HIDX, it)) {
-                            const int r = it * 8 + (lane >> 3), q0 = 2 * (lane & 7);
-                            const int row = strip * 64 + r, col = kChunk * mf + q0 - r;
-                            double *dst = pb.D + (size_t)row * pb.ldD + col;
-                            const bool ok0 = row < M && col >= 0 && col < N, ok1 = row < M && col + 1 >= 0 && col + 1 < N;
-                            if (ok0 && ok1) {
-                                // one 16-byte store at an 8-byte aligned address (global memory takes it; the
-                                // compiler would split it into two 8-byte stores)
-                                typedef double dpair __attribute__((ext_vector_type(2)));
+                    typedef double dpair __attribute__((ext_vector_type(2)));
+                    // interior chunk of a full strip (wave-uniform test): every lane's pair is inside the matrix
+                    const bool interior = (strip * 64 + 63 < M) && (kChunk * mf >= 63) && (kChunk * mf + kChunk <= N);
+                    if (interior) {
+                        static_for<0, 8>([&](auto itc) {
+                            constexpr int it = decltype(itc)::value;
+                            if constexpr (helper_takes_rows(H, HIDX, it)) {
+                                // one 16-byte store at an 8-byte aligned address (global memory takes it; the compiler
+                                // would split it into two 8-byte stores).  The s_nop is the wait state a store of more
+                                // than 8 bytes needs before its data registers may be overwritten: the compiler's hazard
+                                // recognizer does not look inside inline asm.
+                                double *dst = drow + (size_t)(it * 8) * pb.ldD + (kChunk * mf - it * 8);
                                 const dpair pv = {v0[it], v1[it]};
-                                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(pv) : "memory");
-                            } else {  // the two ends of a row
-                                if (ok0) dst[0] = v0[it];
-                                if (ok1) dst[1] = v1[it];
+                                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(pv) : "memory");
                             }
-                        }
-                    });
+                        });
+                    } else {
+                        static_for<0, 8>([&](auto itc) {
+                            constexpr int it = decltype(itc)::value;
+                            if constexpr (helper_takes_rows(H, HIDX, it)) {
+                                const int r = it * 8 + (lane >> 3), q0 = 2 * (lane & 7);
+                                const int row = strip * 64 + r, col = kChunk * mf + q0 - r;
+                                double *dst = drow + (size_t)(it * 8) * pb.ldD + (kChunk * mf - it * 8);
+                                const bool ok0 = row < M && col >= 0 && col < N, ok1 = row < M && col + 1 >= 0 && col + 1 < N;
+                                if (ok0 && ok1) {
+                                    const dpair pv = {v0[it], v1[it]};
+                                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(pv) : "memory");
+                                } else {  // the two ends of a row
+                                    if (ok0) dst[0] = v0[it];
+                                    if (ok1) dst[1] = v1[it];
+                                }
+                            }
+                        });
+                    }
                 }
                 // ---- helper 0: where did the best path of every cell of that chunk enter the strip?  The recurrence
                 //      needs nothing but the step codes: a cell hands on the entry column of the predecessor it chose;
