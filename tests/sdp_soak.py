@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Soak test of the strip DP (csrc/sdp.h) on the GPU box: seeded random DTW shapes (1 .. ~1500 rows / columns, batches,
+float32 / float64 inputs, shared or per-pair b) and WTW windows of 65 .. 900 frames, against the CPU oracle --
+cost, acc_cost, back-pointers, paths, pointers, bit for bit.  The pytest suite runs a shortened form.
+
+    python3 tests/sdp_soak.py [n_trials] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(n_trials=60, seed=5, verbose=True):
+    import torch
+    import oracle
+    from real_time_audio_sync_amd import synth
+    from real_time_audio_sync_amd.dtw import dtw_batch
+    from real_time_audio_sync_amd.otw_batch import frames_tensor
+    from real_time_audio_sync_amd.wtw import BatchedWTW
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(seed)
+    t0 = time.time()
+    checked = 0
+    for trial in range(n_trials):
+        if trial % 3 != 2:
+            # ---- DTW
+            M = int(rs.choice([1, 2, 5, 63, 64, 65, 127, 128, 129, 200, 333, 511, 640, 900, 1500]))
+            N = int(rs.choice([1, 2, 3, 15, 16, 17, 31, 48, 63, 64, 65, 100, 257, 700, 1100]))
+            B = int(rs.choice([1, 1, 2, 3]))
+            tdt = torch.float32 if rs.rand() < 0.5 else torch.float64
+            shared_b = bool(rs.rand() < 0.5)
+            a_np = [synth.synth_ref(M, seed=1000 * trial + k) * (0.5 + rs.rand()) for k in range(B)]
+            b_np = [synth.synth_ref(N, seed=1000 * trial + 500 + k) for k in range(1 if shared_b else B)]
+            a = torch.stack([frames_tensor(x, dev, tdt) for x in a_np])
+            b = frames_tensor(b_np[0], dev, tdt) if shared_b else torch.stack([frames_tensor(x, dev, tdt) for x in b_np])
+            cost, acc, back, path, plen = dtw_batch(a, b)
+            torch.cuda.synchronize()
+            for k in range(B):
+                ak, bk = a_np[k], b_np[0 if shared_b else k]
+                if tdt == torch.float32:
+                    ak, bk = ak.astype(np.float32).astype(np.float64), bk.astype(np.float32).astype(np.float64)
+                ocost, oacc, opath, oback = oracle.dtw(ak, bk)
+                tag = ("dtw", trial, M, N, B, str(tdt), shared_b, k)
+                n = int(plen[k])
+                assert np.array_equal(path[k, :n].cpu().numpy(), opath), tag
+                assert np.array_equal(acc[k].cpu().numpy(), oacc), tag
+                assert np.array_equal(cost[k].cpu().numpy(), ocost), tag
+                assert np.array_equal(back[k].cpu().numpy(), oback), tag
+                checked += 1
+        else:
+            # ---- WTW, windows on the strip-DP path
+            W = int(rs.choice([65, 66, 100, 127, 128, 129, 200, 321, 640, 900]))
+            hopf = int(rs.randint(max(1, W // 6), W + 1))
+            Mref = int(W + rs.choice([2, 10, 150, 400]))
+            B = int(rs.choice([1, 2]))
+            ref = synth.synth_ref(Mref, seed=trial)
+            lives = []
+            for k in range(B):
+                lv = synth.synth_live(ref, seed=700 + 10 * trial + k, lo=float(rs.uniform(0.6, 1.0)), hi=float(rs.uniform(1.0, 1.6)))
+                if lv.shape[1] == 0:
+                    lv = ref[:, :1].copy()
+                lv = lv * (0.5 + rs.rand(1, lv.shape[1]))
+                if rs.rand() < 0.3 and lv.shape[1] > 3:
+                    lv[:, int(rs.randint(0, lv.shape[1]))] = 0.0   # a silent frame: NaN costs (wtw.py:169)
+                lives.append(lv)
+            keep = bool(rs.rand() < 0.4)
+            eng = BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev), W, hopf, B, keep_last_d=keep)
+            tmax = max(l.shape[1] for l in lives)
+            cols = np.zeros((B, tmax, 12))
+            for k, l in enumerate(lives):
+                cols[k, : l.shape[1]] = l.T
+            n_new = torch.tensor([l.shape[1] for l in lives], dtype=torch.int32, device=dev)
+            cut = int(rs.randint(0, tmax + 1))
+            if cut > 0:
+                eng.push(torch.from_numpy(cols[:, :cut].copy()).to(dev), torch.clamp(n_new, max=cut), precheck=True)
+            if cut < tmax:
+                eng.push(torch.from_numpy(cols[:, cut:].copy()).to(dev), torch.clamp(n_new - cut, min=0), precheck=True)
+            for k, l in enumerate(lives):
+                o = oracle.WtwOracle(ref, W, hopf)
+                with np.errstate(all="ignore"):
+                    for q in range(l.shape[1]):
+                        if q == 0 or q == cut:
+                            if o.insert_precheck() != oracle.RUNNING:
+                                break
+                        if o.push_col(l[:, q]) != oracle.RUNNING:
+                            break
+                st, so = eng.state(k), o.state
+                tag = ("wtw", trial, W, hopf, Mref, B, k, cut)
+                assert np.array_equal(eng.path(k), o.path), tag
+                assert (st["live_ptr"], st["ref_ptr"], st["windows"]) == (so["live_ptr"], so["ref_ptr"], o.counters["windows"]), tag
+                assert (st["status"] != 0) == (so["status"] != 0), tag
+                checked += 1
+            eng.close()
+        if verbose and trial % 10 == 9:
+            print("trial %d: %d problems checked, %.0f s" % (trial + 1, checked, time.time() - t0), flush=True)
+    return checked
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    print("checked", run(n, seed), "problems bit-exact against the oracle")

@@ -148,3 +148,10 @@ def test_dtw_batched_pipelines_side_by_side():
             assert np.array_equal(acc[k].cpu().numpy(), oacc), (str(tdt), k)
             assert np.array_equal(cost[k].cpu().numpy(), ocost), (str(tdt), k)
             assert np.array_equal(back[k].cpu().numpy(), oback), (str(tdt), k)
+
+
+def test_strip_dp_soak_short():
+    """tests/sdp_soak.py, shortened: seeded random DTW shapes / batches / dtypes and WTW windows on the strip-DP path,
+    everything bit-exact against the oracle (cost, acc_cost, back-pointers, paths, pointers)."""
+    import sdp_soak
+    assert sdp_soak.run(45, seed=17, verbose=False) >= 45
