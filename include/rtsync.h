@@ -94,9 +94,10 @@ typedef struct rts_otw rts_otw;
  * LiveNoteV2.__init__ (livenote_v2.py:8-40) for B streams at once.  `ref_dev` ([N][F], dtype
  * `ref_dtype`) is held by reference like otw_eran.py:17 and must outlive the handle.  Instead of the
  * reference's dense (2N x N) cost/acc matrices the handle keeps two (c+1)-cell bands per stream.
- * F must be 12.  Supported band widths: 1 <= c <= 500 everywhere; 500 < c <= 1012 for rts_otw_run with float32
- * reference and live features (the 1024-frame live ring then still fits LDS; other calls return
- * RTS_ERR_UNSUPPORTED with a message). */
+ * F must be 12.  Supported band widths: 1 <= c <= 1012.  Above c = 500 only the default pipelined
+ * kernel exists (its helper waves read live frames from global memory instead of an LDS ring), so the
+ * dense mirror (rts_otw_enable_dense / rts_otw_replay_dense) and RTS_OTW_SPEC=0 return
+ * RTS_ERR_UNSUPPORTED with a message there, and live buffers must be 16-byte aligned. */
 int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int c, int max_run_count,
                    int variant, int cost_kind, rts_otw **out);
 int rts_otw_destroy(rts_otw *h);

@@ -34,6 +34,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -64,6 +65,16 @@ struct OtwArgs {
 // widen back exactly, so results are identical while the plain kernel's LDS drops from 131 KB to 74 KB at
 // W = 512 -- 58 KB for the pipelined kernel, which keeps no reference ring -- and two workgroups share a CU:
 // what matters beyond 256 concurrent streams).
+// Ring element type tag of the pipelined kernel's second flavour: no live ring in LDS at all, the helper waves read
+// live frames from global memory like reference frames (otw_live_frame).  Taken for float64 features (a float64 ring
+// costs 49 KB at W = 512 and with it three of four workgroups per CU: B = 4096 75.2 -> 60.7 ms, B = 512 9.35 -> 7.52 ms)
+// and for the 1024-cell window (no ring of either type fits beside its bands).  With float32 features at W <= 512 the
+// ring stays: 4.50 vs 4.62 ms at B = 64, 46.9 vs 48.4 ms at B = 4096 (same-call A/B, one box).
+struct LiveFromGlobal {};
+template <typename RT> struct RingElem { using type = RT; };
+template <> struct RingElem<LiveFromGlobal> { using type = float; };
+template <typename RT> constexpr bool kHasLiveRing = !std::is_same<RT, LiveFromGlobal>::value;
+
 template <int W, typename RT>
 struct OtwLds {
     static constexpr int L = W / 64;     // cells per lane in the chain phase
@@ -72,7 +83,8 @@ struct OtwLds {
     double C[SWZ];      // acc[.][j]  column band
     double Dr[2][SWZ];  // row strip cell costs: [buf] = this step's, [buf^1] = being pre-computed for the next
     double Dc[2][SWZ];
-    RT livew[kF][W];  // feature-major ring of live frames      (index x & (W-1))
+    using E = typename RingElem<RT>::type;
+    E livew[kF][kHasLiveRing<RT> ? W : 1];  // feature-major ring of live frames (index x & (W-1))
     // column chain wave -> wave 0, read back in one go
     double cfresh_min;
     double corner_pa;  // Both step: acc[t-1][jn-1] + 2 d(t, jn), stashed before column jn-1 is overwritten
@@ -85,7 +97,7 @@ struct OtwLds {
     // feature-major ring of reference frames (index y & (W-1)).  Last member: the pipelined kernel reads the
     // reference -- shared by all streams, L2-resident -- straight from global memory in its helper waves and
     // allocates the struct only up to here (58 KB instead of 82 KB at W = 512 with float32 features).
-    RT refw[kF][W];
+    E refw[kF][W];
 };
 
 // Extra LDS of the pipelined kernel (SPEC).  The row band lives in R or ShR and the column band in C or ShC
@@ -436,8 +448,8 @@ template <int W, typename RT>
 __device__ __forceinline__ void otw_commit_live(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e) {
     const int i0 = e.lane, i1 = e.lane + 64;
     const int f0 = k.live_hi + 1 + i0 / kF, f1 = k.live_hi + 1 + i1 / kF;
-    if (f0 < e.live_len) S.livew[i0 % kF][f0 & (W - 1)] = (RT)k.pfl0;
-    if (i1 < kFetch * kF && f1 < e.live_len) S.livew[i1 % kF][f1 & (W - 1)] = (RT)k.pfl1;
+    if (f0 < e.live_len) S.livew[i0 % kF][f0 & (W - 1)] = (typename RingElem<RT>::type)k.pfl0;
+    if (i1 < kFetch * kF && f1 < e.live_len) S.livew[i1 % kF][f1 & (W - 1)] = (typename RingElem<RT>::type)k.pfl1;
     k.live_hi = (k.live_hi + kFetch < e.live_len - 1) ? k.live_hi + kFetch : e.live_len - 1;
     otw_prefetch_live(k, e);
 }
@@ -445,8 +457,8 @@ template <int W, typename RT>
 __device__ __forceinline__ void otw_commit_ref(OtwLds<W, RT> &S, OtwCtl &k, const OtwEnv &e) {
     const int i0 = e.lane, i1 = e.lane + 64;
     const int f0 = k.ref_hi + 1 + i0 / kF, f1 = k.ref_hi + 1 + i1 / kF;
-    if (f0 < e.N) S.refw[i0 % kF][f0 & (W - 1)] = (RT)k.pfr0;
-    if (i1 < kFetch * kF && f1 < e.N) S.refw[i1 % kF][f1 & (W - 1)] = (RT)k.pfr1;
+    if (f0 < e.N) S.refw[i0 % kF][f0 & (W - 1)] = (typename RingElem<RT>::type)k.pfr0;
+    if (i1 < kFetch * kF && f1 < e.N) S.refw[i1 % kF][f1 & (W - 1)] = (typename RingElem<RT>::type)k.pfr1;
     k.ref_hi = (k.ref_hi + kFetch < e.N - 1) ? k.ref_hi + kFetch : e.N - 1;
     otw_prefetch_ref(k, e);
 }
@@ -825,6 +837,31 @@ __device__ __forceinline__ void otw_ref_frame(const OtwEnv &e, int q, double (&r
     }
 }
 
+// The 12 features of this stream's live frame r, from global memory (windows without a live ring).
+__device__ __forceinline__ void otw_live_frame(const OtwEnv &e, int r, double (&lf)[kF]) {
+    if (e.live_f64) {
+        const double2 *p = reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(e.live) + e.live_base +
+                                                             (long long)r * kF);
+#pragma unroll
+        for (int i = 0; i < kF / 2; i++) {
+            const double2 v = p[i];
+            lf[2 * i] = v.x;
+            lf[2 * i + 1] = v.y;
+        }
+    } else {
+        const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(e.live) + e.live_base +
+                                                           (long long)r * kF);
+#pragma unroll
+        for (int i = 0; i < kF / 4; i++) {
+            const float4 v = p[i];
+            lf[4 * i] = (double)v.x;
+            lf[4 * i + 1] = (double)v.y;
+            lf[4 * i + 2] = (double)v.z;
+            lf[4 * i + 3] = (double)v.w;
+        }
+    }
+}
+
 // ---- pipelined kernel ---------------------------------------------------------------------------------------------
 // Cost buffers are keyed by row / column parity instead of by step: Dr[r & 1] holds the costs of live row r and
 // Dc[q & 1] those of reference column q, at ring positions by column / row index.  Invariant at the start of the step
@@ -844,8 +881,12 @@ __device__ __forceinline__ void otw_cost_row(OtwLds<W, RT> &S, const OtwEnv &e, 
     if (k_lo + hidx > k_hi) return;
     double *Drow = S.Dr[r & 1];
     double lf[kF];
+    if constexpr (!kHasLiveRing<RT>) {
+        otw_live_frame(e, r, lf);
+    } else {
 #pragma unroll
-    for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][r & (W - 1)];
+        for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][r & (W - 1)];
+    }
     for (int ka = k_lo + hidx; ka <= k_hi; ka += 2 * hn) {  // two cells in flight per thread
         const int kb = ka + hn;
         const int kb_c = (kb <= k_hi) ? kb : ka;
@@ -876,10 +917,15 @@ __device__ __forceinline__ void otw_cost_col(OtwLds<W, RT> &S, const OtwEnv &e, 
         const int rb_ = ra_ + hn;
         const int rb_c = (rb_ <= r_hi) ? rb_ : ra_;
         double la[kF], lb[kF];
+        if constexpr (!kHasLiveRing<RT>) {
+            otw_live_frame(e, ra_, la);
+            otw_live_frame(e, rb_c, lb);
+        } else {
 #pragma unroll
-        for (int f = 0; f < kF; f++) {
-            la[f] = (double)S.livew[f][ra_ & (W - 1)];
-            lb[f] = (double)S.livew[f][rb_c & (W - 1)];
+            for (int f = 0; f < kF; f++) {
+                la[f] = (double)S.livew[f][ra_ & (W - 1)];
+                lb[f] = (double)S.livew[f][rb_c & (W - 1)];
+            }
         }
         const double da = cell_cost(la, rf, e.euclid), db = cell_cost(lb, rf, e.euclid);
         Dcol[swz<W>(ra_)] = da;
@@ -1120,6 +1166,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     OtwLds<W, RT> &S = *reinterpret_cast<OtwLds<W, RT> *>(smem_raw);
     using LdsT = OtwLds<W, RT>;
+    constexpr bool kNoLiveRing = !kHasLiveRing<RT>;  // live frames read from global memory by the helpers
+    static_assert(SPEC || !kNoLiveRing, "only the pipelined kernel runs without a live ring");
     constexpr size_t kSpecOff = (offsetof(LdsT, refw) + 15) & ~(size_t)15;  // SPEC: no reference ring
     OtwSpecLds<W> &SP = *reinterpret_cast<OtwSpecLds<W> *>(smem_raw + kSpecOff);  // only touched when SPEC
 
@@ -1213,14 +1261,16 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         constexpr int kAhead = SPEC ? 3 : 2;  // frames the first step's cost computations reach past (t, j)
         k.live_hi = (k.t + kAhead < live_len - 1) ? k.t + kAhead : live_len - 1;
         k.ref_hi = (k.j + kAhead < N - 1) ? k.j + kAhead : N - 1;
-        for (int idx = tid; idx < (k.live_hi - lo_l + 1) * kF; idx += NT) {
-            const int fr = lo_l + idx / kF, f = idx % kF;
-            S.livew[f][fr & (W - 1)] = (RT)otw_load_feat(a.live, a.live_f64, e.live_base + (long long)fr * kF + f);
+        if constexpr (!kNoLiveRing) {
+            for (int idx = tid; idx < (k.live_hi - lo_l + 1) * kF; idx += NT) {
+                const int fr = lo_l + idx / kF, f = idx % kF;
+                S.livew[f][fr & (W - 1)] = (typename RingElem<RT>::type)otw_load_feat(a.live, a.live_f64, e.live_base + (long long)fr * kF + f);
+            }
         }
         if (!SPEC) {
             for (int idx = tid; idx < (k.ref_hi - lo_r + 1) * kF; idx += NT) {
                 const int fr = lo_r + idx / kF, f = idx % kF;
-                S.refw[f][fr & (W - 1)] = (RT)otw_load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
+                S.refw[f][fr & (W - 1)] = (typename RingElem<RT>::type)otw_load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
             }
         }
         if (!k.first) {
@@ -1234,14 +1284,18 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
         __syncthreads();
     }
     if (wave == (SPEC ? HW0 : 0)) {  // the wave that will refill the rings starts its first prefetch
-        otw_prefetch_live(k, e);
+        if constexpr (!kNoLiveRing) otw_prefetch_live(k, e);
         if (!SPEC) otw_prefetch_ref(k, e);
     }
     if (wave == 0) {
         if (k.first) {
             double lf[kF], rf[kF];
+            if constexpr (kNoLiveRing) {
+                otw_live_frame(e, 0, lf);
+            } else {
 #pragma unroll
-            for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][0];
+                for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][0];
+            }
             otw_ref_frame(e, 0, rf);
             const double d = rfl(cell_cost(lf, rf, e.euclid));
             if (lane == 0) {
@@ -1326,7 +1380,8 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 RTS_LW_BEGIN();
                 // rings: frames the *next* step's cost work can reach (rows <= pt+3, columns <= jn+3); what this step
                 // reads was made sure of one step ago, and the slots written now are not among it (W >= c + 12)
-                if (wave == HW0) otw_refill<W, RT>(S, k, e, pt + 3, 0, false);  // the reference has no ring here
+                if constexpr (!kNoLiveRing)
+                    if (wave == HW0) otw_refill<W, RT>(S, k, e, pt + 3, 0, false);  // the reference has no ring here
                 if (!(pflags & kPlanHit)) __syncthreads();  // this step's chains have read their cost buffers
                 if (!(pflags & kPlanStop))
                     otw_costs_advance<W, RT>(S, e, pt, j0 + (do_col ? 1 : 0), do_row, do_col, tid - 64 * HW0, NHELP);
@@ -1808,13 +1863,22 @@ static int launch_advance_d(rts_otw *h, const OtwArgs &args, int B, hipStream_t 
 // The dense mirror is a separate instantiation so that the default kernel carries none of its code.
 template <int W, int NW>
 static int launch_advance(rts_otw *h, const OtwArgs &args, int B, hipStream_t s) {
+    if constexpr (W >= 1024) {
+        // no ring fits beside a 1024-cell window's bands: only the pipelined kernel, reading live frames from global memory
+        if constexpr (NW >= 8) {
+            if (args.spec && !args.dense_acc) return launch_advance_d<W, NW, false, LiveFromGlobal, true>(h, args, B, s);
+        }
+        return set_error(RTS_ERR_UNSUPPORTED,
+                         "band widths above 500 (c=%d) run only on the pipelined 8-wave kernel, without the dense mirror",
+                         h->c);
+    }
     if (args.dense_acc) return launch_advance_d<W, NW, true, double, false>(h, args, B, s);
     // float32 rings only when both inputs are float32: every value then widens back exactly
     const bool f32 = !args.ref_f64 && !args.live_f64;
     if constexpr (NW >= 8) {
         if (args.spec)
             return f32 ? launch_advance_d<W, NW, false, float, true>(h, args, B, s)
-                       : launch_advance_d<W, NW, false, double, true>(h, args, B, s);
+                       : launch_advance_d<W, NW, false, LiveFromGlobal, true>(h, args, B, s);
     }
     return f32 ? launch_advance_d<W, NW, false, float, false>(h, args, B, s)
                : launch_advance_d<W, NW, false, double, false>(h, args, B, s);
@@ -1843,11 +1907,7 @@ static int check_device(const rts_otw *h) {
 }
 
 static int launch(rts_otw *h, const OtwArgs &args, hipStream_t s) {
-    if (h->W == 1024 && (args.ref_f64 || args.live_f64 || args.dense_acc))
-        return set_error(RTS_ERR_UNSUPPORTED,
-                         "band widths above 500 (c=%d) keep a 1024-frame live ring in LDS, which fits only as float32: "
-                         "pass float32 reference and live features to rts_otw_run (rts_otw_insert / rts_otw_push and "
-                         "the dense mirror keep float64 and stop at c = 500)", h->c);
+    if ((uintptr_t)args.live & 15) return set_error(RTS_ERR_INVALID, "live features must be 16-byte aligned");
     switch (h->W) {
         case 64: return launch_w<64>(h, args, h->B, h->waves, s);
         case 128: return launch_w<128>(h, args, h->B, h->waves, s);

@@ -50,8 +50,6 @@ def test_golden_cases(gpu, otw_golden, dtype):
         case = parse_case(meta)
         if dtype == "f32" and case["group"] == "G":
             continue  # real chroma is not float32-exact
-        if dtype == "f64" and case["c"] > 500:
-            continue  # bands wider than 500 cells need the float32 rings (include/rtsync.h, rts_otw_create)
         ref = g[case["group"] + "/ref"].astype(np.float64)
         live = g[case["group"] + "/live"].astype(np.float64)
         tdt = torch.float64 if dtype == "f64" else torch.float32
@@ -314,7 +312,7 @@ def test_soak_medium_and_wide_bands(gpu):
 
 
 def test_bands_wider_than_500_cells(gpu):
-    """500 < c <= 1012 run on the 1024-cell window (float32 feature rings, rts_otw_run only): every variant against the
+    """500 < c <= 1012 run on the 1024-cell window: every variant against the
     dense oracle -- path, end state, both live bands -- plus the refusals the header documents.  (The reference-made
     goldens H_otw_c800 / H_livenote_v2_c1000 are covered by test_golden_cases.)"""
     import oracle
@@ -346,12 +344,34 @@ def test_bands_wider_than_500_cells(gpu):
             checked += 1
         eng.close()
     assert checked == 15
-    # float64 features do not fit the 1024-frame ring: refused with a message, not computed wrongly
-    ref, lives = synth.synth_batch(700, 1, seed=5)
-    eng = ob.BatchedOTW(ref, 600, 3, batch=1, dtype=torch.float64)
+    # float64 features and the per-call ingestion paths take the same window (no live ring in LDS: its helper waves
+    # read live frames from global memory), so the drop-in classes work at these widths too
+    ref, lives = synth.synth_batch(900, 2, seed=5)
+    eng = ob.BatchedOTW(ref, 600, 3, batch=2, dtype=torch.float64)
     lv, ln = eng.pack(lives, dtype=torch.float64)
-    with pytest.raises(nat.RtsyncError, match="float32"):
-        eng.run(lv, ln)
+    eng.run(lv, ln)
+    for b, live in enumerate(lives):
+        o = oracle.OtwOracle(ref, 600, 3, oracle.OTW)
+        o.run(live)
+        assert np.array_equal(eng.path(b), o.path), ("f64", b)
+    eng.reset()
+    n_push = 150
+    for f in range(n_push):  # one frame per stream per call (OnlineTimeWarping.insert)
+        eng.insert(torch.from_numpy(np.ascontiguousarray(np.stack([l[:, f] for l in lives]))).to("cuda:0"))
+    for b, live in enumerate(lives):
+        o = oracle.OtwOracle(ref, 600, 3, oracle.OTW)
+        for f in range(n_push):
+            o.insert(live[:, f])
+        assert np.array_equal(eng.path(b), o.path), ("insert", b)
     eng.close()
+    from real_time_audio_sync_amd import otw_eran as otw_mod
+    drop = otw_mod.OnlineTimeWarping(ref, {"c": 700, "max_run_count": 3})
+    o = oracle.OtwOracle(ref, 700, 3, oracle.OTW)
+    for f in range(120):
+        drop.insert(lives[0][:, f])
+        o.insert(lives[0][:, f])
+    assert np.array_equal(np.asarray(drop.path), o.path)
+    with pytest.raises(nat.RtsyncError, match="dense"):  # the dense mirror stops at c = 500
+        drop.acc_cost
     with pytest.raises(nat.RtsyncError):
         ob.BatchedOTW(ref, 1013, 3, batch=1, dtype=torch.float32)
