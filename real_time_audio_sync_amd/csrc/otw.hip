@@ -1825,6 +1825,7 @@ struct rts_otw {
     double *dense_acc, *dense_cost;  // caller-owned, optional
     int spec;           // 1: pipelined kernel (needs 8 waves and no dense mirror); 0: plain kernel
     int device;         // the HIP device the handle's buffers live on (one handle = one device)
+    int cus;            // its compute units
     const void *attr_fn[8];  // kernel instantiations whose dynamic-LDS limit is already raised on `device`
     // what the handle has consumed since the last reset, for rts_otw_replay_dense
     int src_kind;       // 0 nothing, 1 the buffers of the last rts_otw_run, 2 the handle-owned history, 3 mixed
@@ -1876,9 +1877,13 @@ static int launch_advance(rts_otw *h, const OtwArgs &args, int B, hipStream_t s)
     // float32 rings only when both inputs are float32: every value then widens back exactly
     const bool f32 = !args.ref_f64 && !args.live_f64;
     if constexpr (NW >= 8) {
-        if (args.spec)
-            return f32 ? launch_advance_d<W, NW, false, float, true>(h, args, B, s)
-                       : launch_advance_d<W, NW, false, LiveFromGlobal, true>(h, args, B, s);
+        if (args.spec) {
+            if (f32) return launch_advance_d<W, NW, false, float, true>(h, args, B, s);
+            // float64 features: the ring (one workgroup per CU at W = 512) while every stream has a CU to itself
+            // (B = 64: 4.67 vs 4.93 ms), no ring and up to four workgroups per CU beyond
+            return (B <= h->cus) ? launch_advance_d<W, NW, false, double, true>(h, args, B, s)
+                                 : launch_advance_d<W, NW, false, LiveFromGlobal, true>(h, args, B, s);
+        }
     }
     return f32 ? launch_advance_d<W, NW, false, float, false>(h, args, B, s)
                : launch_advance_d<W, NW, false, double, false>(h, args, B, s);
@@ -1987,7 +1992,8 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     h->live_cap = 2 * N;
     h->path_cap = 3 * N + 8;  // one point per decide(); decides <= row strips + column strips <= 2N + N
     hipError_t e;
-    if ((e = hipGetDevice(&h->device)) != hipSuccess) {
+    if ((e = hipGetDevice(&h->device)) != hipSuccess ||
+        (e = hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device)) != hipSuccess) {
         free(h);
         return set_error(RTS_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e));
     }
