@@ -214,6 +214,51 @@ __device__ __forceinline__ double wave_min(double x) {
     return wave_bcast(x, 63);
 }
 
+// LDS access with the row offset as an instruction immediate (the pipelined kernel's strips; see strip_chain).  The
+// compiler does not see these as memory operations it must wait for: chain_wait() is the s_waitcnt, tied to the loaded
+// values so that no use can move above it.
+__device__ __forceinline__ unsigned lds_addr(const double *p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const double *)p;
+}
+template <int OFF>
+__device__ __forceinline__ double lds_read_imm(unsigned addr) {
+    double r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_imm(unsigned addr, double v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int L, int R, int M = 0>
+__device__ __forceinline__ void chain_load(unsigned bA, unsigned bB, unsigned dA, unsigned dB, double (&prevb)[L + 1],
+                                           double (&D)[L]) {
+    if constexpr (M <= L) {
+        constexpr int off = ((R + M) & (L - 1)) * 65 * 8;
+        constexpr bool wrap = (R + M) >= L;
+        prevb[M] = lds_read_imm<off>(wrap ? bB : bA);
+        if constexpr (M > 0) D[M - 1] = lds_read_imm<off>(wrap ? dB : dA);
+        chain_load<L, R, M + 1>(bA, bB, dA, dB, prevb, D);
+    }
+}
+template <int L, int M = 0>
+__device__ __forceinline__ void chain_wait(double (&prevb)[L + 1], double (&D)[L]) {
+    if constexpr (M == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (M <= L) {
+        asm volatile("" : "+v"(prevb[M]));
+        if constexpr (M < L) asm volatile("" : "+v"(D[M]));
+        chain_wait<L, M + 1>(prevb, D);
+    }
+}
+template <int L, int R, int M = 1>
+__device__ __forceinline__ void chain_store(unsigned oA, unsigned oB, const double (&v)[L], double v_top) {
+    if constexpr (M <= L) {
+        constexpr int off = ((R + M) & (L - 1)) * 65 * 8;
+        lds_write_imm<off>((R + M) >= L ? oB : oA, (M == L) ? v_top : v[M - 1]);
+        chain_store<L, R, M + 1>(oA, oB, v, v_top);
+    }
+}
+
 // One strip, one wave.  Cell i (band position k = k1 + i, i in [0, n)) gets
 //     a_i   = min(band[k] + d_i, band[k-1] + 2 d_i)      the two predecessors outside the strip
 //                                                        (band = previous row for a row strip,
@@ -249,25 +294,43 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
     // cell (lane, m) sits at band position q + L*lane with q = k1 + m wave-uniform, i.e. at LDS slot
     // (q mod L)*65 + ((q / L + lane) mod 64); slot[m] addresses position k - 1 of cell m
     int slot[L + 1];
-#pragma unroll
-    for (int m = 0; m <= L; m++) {
-        const int q = k1 + m - 1 + W;  // + W keeps q >= 0 without changing the slot
-        slot[m] = (q & (L - 1)) * 65 + (((q >> LOG_L) + lane) & 63);
-    }
     const int nloc = n - L * lane;  // cell m of this lane is inside the strip iff m < nloc
     double prevb[L + 1], D[L], v[L];
-#pragma unroll
-    for (int m = 0; m <= L; m++) {  // positions k-1 .. k+L-1
-        if (GUARD) {
-            const int q0 = k1 - 1 + W;
-            const int safe = (q0 & (L - 1)) * 65 + ((q0 >> LOG_L) & 63);
-            prevb[m] = band[(m <= nloc) ? slot[m] : safe];  // position index L*lane + m - 1 <= n - 1
-        } else {
-            prevb[m] = band[slot[m]];
+    // GUARD strips (the two per step of the pipelined kernel) address their slots through one of L code variants,
+    // selected by the strip start's row in the swizzle: inside a variant every row offset is an immediate and only
+    // the two column words (this lane's and the next one's) sit in registers.  Cells past the strip end read
+    // whatever their slots hold -- possibly a corner slot wave 0 is writing at that moment; their cost is +inf
+    // below, so the value never reaches a result (an aligned 8-byte LDS access is one operation, and even a NaN is
+    // dropped by v_min_f64).
+    const int q0 = k1 - 1 + W;  // + W keeps it >= 0 without changing the slot
+    const int r0 = q0 & (L - 1);
+    const int colA = ((q0 >> LOG_L) + lane) & 63, colB = (colA + 1) & 63;
+    if constexpr (GUARD) {
+        const unsigned bA = lds_addr(band + colA), bB = lds_addr(band + colB), dA = lds_addr(Dv + colA), dB = lds_addr(Dv + colB);
+        switch (r0) {
+#define RTS_CHAIN_LOAD(R)                                                        \
+    case R:                                                                      \
+        if constexpr (R < L) chain_load<L, R>(bA, bB, dA, dB, prevb, D);         \
+        break;
+            RTS_CHAIN_LOAD(0) RTS_CHAIN_LOAD(1) RTS_CHAIN_LOAD(2) RTS_CHAIN_LOAD(3) RTS_CHAIN_LOAD(4) RTS_CHAIN_LOAD(5)
+            RTS_CHAIN_LOAD(6) RTS_CHAIN_LOAD(7) RTS_CHAIN_LOAD(8) RTS_CHAIN_LOAD(9) RTS_CHAIN_LOAD(10) RTS_CHAIN_LOAD(11)
+            RTS_CHAIN_LOAD(12) RTS_CHAIN_LOAD(13) RTS_CHAIN_LOAD(14) RTS_CHAIN_LOAD(15)
+#undef RTS_CHAIN_LOAD
         }
-    }
+        chain_wait<L>(prevb, D);
+    } else {
+        // cell (lane, m) sits at band position q + L*lane with q = k1 + m wave-uniform, i.e. at LDS slot
+        // (q mod L)*65 + ((q / L + lane) mod 64); slot[m] addresses position k - 1 of cell m
 #pragma unroll
-    for (int m = 0; m < L; m++) D[m] = Dv[slot[m + 1]];
+        for (int m = 0; m <= L; m++) {
+            const int q = k1 + m - 1 + W;
+            slot[m] = (q & (L - 1)) * 65 + (((q >> LOG_L) + lane) & 63);
+        }
+#pragma unroll
+        for (int m = 0; m <= L; m++) prevb[m] = band[slot[m]];  // positions k-1 .. k+L-1
+#pragma unroll
+        for (int m = 0; m < L; m++) D[m] = Dv[slot[m + 1]];
+    }
     prevb[0] = (k1 == 0 && lane == 0) ? inf : prevb[0];  // row/column 0 has no diagonal predecessor
     // speculative strips only: position k1-1 is being rewritten with the sentinel by wave 0 in this very step
     if (GUARD && ALT) prevb[0] = (prev0_xin && lane == 0) ? x_in : prevb[0];
@@ -308,12 +371,25 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
             v[m] = vmin(v[m], q);
         }
     }
+    if constexpr (GUARD) {
+        // a shadow strip is installed as it is: position k1-1 (= k1+W-1 on the ring, lane 63's last cell, always
+        // past the strip end) gets the value an in-place strip's caller writes there afterwards
+        const double v_top = (lane == 63) ? x_in : v[L - 1];
+        const unsigned oA = lds_addr(band_out + colA), oB = lds_addr(band_out + colB);
+        switch (r0) {
+#define RTS_CHAIN_STORE(R)                                                       \
+    case R:                                                                      \
+        if constexpr (R < L) chain_store<L, R>(oA, oB, v, v_top);                \
+        break;
+            RTS_CHAIN_STORE(0) RTS_CHAIN_STORE(1) RTS_CHAIN_STORE(2) RTS_CHAIN_STORE(3) RTS_CHAIN_STORE(4)
+            RTS_CHAIN_STORE(5) RTS_CHAIN_STORE(6) RTS_CHAIN_STORE(7) RTS_CHAIN_STORE(8) RTS_CHAIN_STORE(9)
+            RTS_CHAIN_STORE(10) RTS_CHAIN_STORE(11) RTS_CHAIN_STORE(12) RTS_CHAIN_STORE(13) RTS_CHAIN_STORE(14)
+            RTS_CHAIN_STORE(15)
+#undef RTS_CHAIN_STORE
+        }
+    } else {
 #pragma unroll
-    for (int m = 0; m < L; m++) band_out[slot[m + 1]] = v[m];
-    // a shadow strip is installed as it is: position k1-1 (= k1+W-1 on the ring, lane 63's last cell, always
-    // past the strip end) gets the value an in-place strip's caller writes there afterwards
-    if (GUARD) {
-        if (lane == 63) band_out[slot[L]] = x_in;
+        for (int m = 0; m < L; m++) band_out[slot[m + 1]] = v[m];
     }
     if (DENSE) {  // optional: mirror the strip into the reference's dense matrices (cell i at base + i*stride)
 #pragma unroll
