@@ -638,6 +638,12 @@ __device__ __forceinline__ void otw_decide(const double *R, const double *C, Otw
         x = cidx;
         y = jj;
     }
+    // every lane holds the same control state; saying so lets the direction logic below, and the next plan that
+    // follows from it, run on the scalar unit
+    x = __builtin_amdgcn_readfirstlane(x);
+    y = __builtin_amdgcn_readfirstlane(y);
+    k.run_count = __builtin_amdgcn_readfirstlane(k.run_count);
+    k.prev = __builtin_amdgcn_readfirstlane(k.prev);
     bool append = true;
     if (e.variant == RTS_VARIANT_LIVENOTE_V2)  // livenote_v2.py:198
         append = (k.n_path == 0) || (x > k.last_x && y >= k.last_y);
@@ -1526,7 +1532,9 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
 #endif
             for (;;) {
                 RTS_STAMP2(0);
-                const int pt = pl.t, j0 = pl.j0;  // wave 0 wrote the plan itself
+                // wave 0 wrote the plan itself; pinned to SGPRs so that the step's addressing and branches are scalar
+                const int pt = __builtin_amdgcn_readfirstlane(pl.t), j0 = __builtin_amdgcn_readfirstlane(pl.j0);
+                pl.flags = __builtin_amdgcn_readfirstlane(pl.flags);
                 const int pflags = otw_resolve_plan(pl.flags, pt, c, &SP.col[sp]);
                 if (pflags & kPlanExit) break;
                 if ((pl.flags & kPlanHitIf) && (pflags & kPlanHit)) {  // resolved to a hit: both shadows become bands
