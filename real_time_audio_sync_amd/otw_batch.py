@@ -30,6 +30,20 @@ def frames_tensor(x, device, dtype=None):
     return x.to(device).t().contiguous()
 
 
+def _on_device(fn):
+    """Run a method with the handle's device current (a handle belongs to the device it was created on; with several
+    devices driven from one process -- shard.ShardedOTW -- another one may be current when the call comes)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kwargs)
+    return wrapped
+
+
 class BatchedOTW:
     """``ref``: (12, N) feature-major array/tensor, or a device tensor already [N][12] with
     ``frame_major=True``.  ``variant``: 'otw' | 'livenote' | 'livenote_v2'."""
@@ -39,6 +53,8 @@ class BatchedOTW:
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedOTW needs a ROCm GPU (no CPU fallback)")
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         torch.cuda.set_device(self.device)
         if frame_major:
             self.ref = ref.to(self.device).contiguous()
@@ -60,7 +76,11 @@ class BatchedOTW:
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            nat.lib.rts_otw_destroy(h)
+            if torch.cuda.current_device() == self.device.index:
+                nat.lib.rts_otw_destroy(h)
+            else:
+                with torch.cuda.device(self.device):
+                    nat.lib.rts_otw_destroy(h)
 
     __del__ = close
 
@@ -80,6 +100,7 @@ class BatchedOTW:
         lens = torch.tensor([int(l.shape[1]) for l in lives], dtype=torch.int32)
         return buf.to(self.device), lens.to(self.device)
 
+    @_on_device
     def run(self, live_dev, live_len_dev, mode="insert"):
         """Asynchronous on the current stream.  live_dev: [B][T_max][12]; live_len_dev: int32 [B]."""
         assert live_dev.is_contiguous() and live_dev.shape[0] == self.B and live_dev.shape[2] == 12
@@ -90,6 +111,7 @@ class BatchedOTW:
                                       nat.MODE_SET_LIVE if mode == "set_live" else nat.MODE_INSERT_LOOP,
                                       self._stream()))
 
+    @_on_device
     def insert(self, frames_dev, active_dev=None):
         """One frame per stream: frames_dev [B][12]; active_dev optional uint8 [B]."""
         assert frames_dev.is_contiguous() and tuple(frames_dev.shape) == (self.B, 12)
@@ -98,6 +120,7 @@ class BatchedOTW:
                                          active_dev.data_ptr() if active_dev is not None else None,
                                          self._stream()))
 
+    @_on_device
     def push(self, frames_dev, n_new_dev=None):
         """Several frames per stream: frames_dev [B][n_max][12]; n_new_dev optional int32 [B]."""
         assert frames_dev.is_contiguous() and frames_dev.shape[0] == self.B and frames_dev.shape[2] == 12
@@ -106,11 +129,13 @@ class BatchedOTW:
                                        int(frames_dev.shape[1]), n_new_dev.data_ptr() if n_new_dev is not None else None,
                                        self._stream()))
 
+    @_on_device
     def reset(self):
         self._version += 1
         nat.check(nat.lib.rts_otw_reset(self._h, self._stream()))
 
     # ---- results ------------------------------------------------------------------------------
+    @_on_device
     def states(self):
         out = np.zeros((self.B, nat.STATE_LEN), dtype=np.int32)
         nat.check(nat.lib.rts_otw_read_states(self._h, out.ctypes.data, self._stream()))
@@ -126,6 +151,7 @@ class BatchedOTW:
                     row_strips=int(s[nat.ST_ROW_STRIPS]), col_strips=int(s[nat.ST_COL_STRIPS]), cells=cells,
                     path_truncated=int(s[nat.ST_PATH_TRUNCATED]), band_recomputes=int(s[nat.ST_BAND_RECOMPUTES]))
 
+    @_on_device
     def path(self, b=0):
         n = ctypes.c_int(0)
         nat.check(nat.lib.rts_otw_read_path(self._h, b, None, 0, ctypes.byref(n), self._stream()))
@@ -138,12 +164,14 @@ class BatchedOTW:
     def paths(self):
         return [self.path(b) for b in range(self.B)]
 
+    @_on_device
     def bands(self, b=0):
         rb = np.empty(self.c + 1)
         cb = np.empty(self.c + 1)
         nat.check(nat.lib.rts_otw_read_bands(self._h, b, rb.ctypes.data, cb.ctypes.data, self._stream()))
         return rb, cb
 
+    @_on_device
     def enable_dense(self):
         """Allocate and attach the reference's dense (2N x N) acc_cost / cost matrices per stream
         (float64 device tensors [B][2N][N]); every evaluated cell is mirrored into them."""
@@ -153,6 +181,7 @@ class BatchedOTW:
                                             self._stream()))
         return self.dense_acc, self.dense_cost
 
+    @_on_device
     def replay_dense(self):
         """The reference's dense (2N x N) acc_cost / cost matrices (float64 device tensors [B][2N][N]) for
         everything consumed since the last reset, recomputed on demand by a second pass over the kept frames
@@ -162,6 +191,7 @@ class BatchedOTW:
         nat.check(nat.lib.rts_otw_replay_dense(self._h, acc.data_ptr(), cost.data_ptr(), self._stream()))
         return acc, cost
 
+    @_on_device
     def set_waves(self, waves):
         nat.check(nat.lib.rts_otw_set_waves(self._h, int(waves)))
 

@@ -43,3 +43,71 @@ def gather_paths(local_paths, dst=0):
     if rank != dst:
         return None
     return [p for chunk in out for p in chunk]
+
+
+class ShardedOTW:
+    """One host process driving several devices ("one Python process driving 8 devices with per-device
+    streams is enough"): the streams are cut into contiguous slices (``partition``), every device gets its own replica
+    of the reference and its own ``BatchedOTW``, launches are asynchronous per device, and nothing is exchanged between
+    devices.  ``devices``: list of device indices (default: all visible ones); stream b lives on the device whose
+    slice contains it.  The interface follows BatchedOTW's, with global stream indices."""
+
+    def __init__(self, ref, c, max_run_count, batch, devices=None, **kwargs):
+        from .otw_batch import BatchedOTW
+        if devices is None:
+            devices = list(range(torch.cuda.device_count()))
+        if not devices:
+            raise RuntimeError("ShardedOTW needs at least one ROCm GPU (no CPU fallback)")
+        self.B = int(batch)
+        before = torch.cuda.current_device()
+        self.slices, self.engines = [], []
+        for r, d in enumerate(devices):
+            lo, hi = partition(self.B, len(devices), r)
+            if hi > lo:
+                self.slices.append((lo, hi))
+                self.engines.append(BatchedOTW(ref, c, max_run_count, batch=hi - lo, device="cuda:%d" % int(d), **kwargs))
+        torch.cuda.set_device(before)
+
+    def _locate(self, b):
+        for (lo, hi), eng in zip(self.slices, self.engines):
+            if lo <= b < hi:
+                return eng, b - lo
+        raise IndexError("stream %d of %d" % (b, self.B))
+
+    def pack(self, lives, dtype=None):
+        """List of B (12, T_b) arrays -> one (frames, lengths) pair per device, resident there."""
+        assert len(lives) == self.B
+        return [eng.pack(lives[lo:hi], dtype) for (lo, hi), eng in zip(self.slices, self.engines)]
+
+    def run(self, packed, mode="insert"):
+        """Launch every device's slice (asynchronous: returns once all launches are queued)."""
+        for eng, (lv, ln) in zip(self.engines, packed):
+            eng.run(lv, ln, mode=mode)
+
+    def reset(self):
+        for eng in self.engines:
+            eng.reset()
+
+    def synchronize(self):
+        for eng in self.engines:
+            torch.cuda.synchronize(eng.device)
+
+    def path(self, b):
+        eng, i = self._locate(b)
+        return eng.path(i)
+
+    def paths(self):
+        return [p for eng in self.engines for p in eng.paths()]
+
+    def state(self, b):
+        eng, i = self._locate(b)
+        return eng.state(i)
+
+    def bands(self, b):
+        eng, i = self._locate(b)
+        return eng.bands(i)
+
+    def close(self):
+        for eng in self.engines:
+            eng.close()
+        self.engines = []

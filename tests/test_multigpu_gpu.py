@@ -41,3 +41,39 @@ def test_bench_over_rccl_on_all_devices():
     r = json.loads(line)
     assert r["n_gpus"] == n and r["scaling"] == "weak" and r["config"]["streams_total"] == 8 * n
     assert r["parity"]["path_mismatches"] == 0 and r["value"] > 0
+
+
+def test_one_process_many_devices():
+    """shard.ShardedOTW: one host process, one BatchedOTW per device, contiguous stream slices, no exchange.  Runs on
+    every visible device, and always also as two slices on device 0 (which exercises the slicing, the per-handle
+    device switch and two handles side by side on a one-GPU box); results must equal the oracle's."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import numpy as np
+    import oracle
+    from real_time_audio_sync_amd import shard, synth
+    ref, lives = synth.synth_batch(400, 7, seed=77)
+    lives[4] = lives[4][:, :150]
+    want = []
+    for live in lives:
+        o = oracle.OtwOracle(ref, 100, 3)
+        o.run(live)
+        want.append(np.asarray(o.path))
+    layouts = [[0, 0], [0, 0, 0]]
+    if torch.cuda.device_count() > 1:
+        layouts.append(list(range(min(torch.cuda.device_count(), 8))))
+    for devices in layouts:
+        eng = shard.ShardedOTW(ref, 100, 3, batch=7, devices=devices, dtype=torch.float32)
+        assert [hi - lo for lo, hi in eng.slices] == [hi - lo for lo, hi in
+                                                      (shard.partition(7, len(devices), r) for r in range(len(devices)))]
+        packed = eng.pack(lives)
+        eng.run(packed)
+        eng.synchronize()
+        got = eng.paths()
+        assert len(got) == 7
+        for b in range(7):
+            assert np.array_equal(got[b], want[b]), (devices, b)
+            assert np.array_equal(eng.path(b), want[b])
+            assert eng.state(b)["n_path"] == len(want[b])
+        eng.close()
