@@ -62,9 +62,6 @@ def main():
     tag = sys.argv[1]
     out = os.path.join(ROOT, "gpurun_out", "profile_" + tag)
     os.makedirs(out, exist_ok=True)
-    final = run(["python3", "bench.py"], os.path.join(out, tag + "_bench_final.json"))
-    print("bench: %.3f ms/step, %.3e frames/s" % (final["ms_per_step"], final["value"]), flush=True)
-
     d = os.path.join(out, "trace")
     # --no-cpu: the CPU legs fork worker processes, which must not happen under the profiler's preloaded runtime
     under = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--",
@@ -87,12 +84,6 @@ def main():
         v, c = pmc_pass(out, name, counters)
         pmc.update(v)
         n.update(c)
-    summary = {"kernel": krow["Name"], "kernel_trace": {k: krow[k] for k in ("Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")},
-               "pmc_mean_per_dispatch": pmc, "pmc_dispatches": n,
-               "bench_final": {k: final[k] for k in ("value", "ms_per_step")},
-               "bench_under_rocprof_launch_ms": under["roofline"]["launch_ms"]}
-    with open(os.path.join(out, tag + "_pmc.json"), "w") as f:
-        json.dump(summary, f, indent=1)
     traffic = {
         "hbm_bytes_per_launch": int((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024),
         "FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"],
@@ -101,8 +92,19 @@ def main():
                    "between the undoubled and the doubled sum",
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 3 --warmup 1 --no-cpu, "
                   "kernel %s, %s (tools/collect_profile.py)" % (krow["Name"], tag)}
-    with open(os.path.join(out, "otw_traffic.json"), "w") as f:
-        json.dump(traffic, f, indent=1)
+    # the un-profiled bench line last, reading the traffic figure this very pass measured (bench.py takes
+    # roofline.traffic from profiles/otw_traffic.json), so that the two files agree
+    for path in (os.path.join(out, "otw_traffic.json"), os.path.join(ROOT, "profiles", "otw_traffic.json")):
+        with open(path, "w") as f:
+            json.dump(traffic, f, indent=1)
+    final = run(["python3", "bench.py"], os.path.join(out, tag + "_bench_final.json"))
+    print("bench: %.3f ms/step, %.3e frames/s" % (final["ms_per_step"], final["value"]), flush=True)
+    summary = {"kernel": krow["Name"], "kernel_trace": {k: krow[k] for k in ("Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")},
+               "pmc_mean_per_dispatch": pmc, "pmc_dispatches": n,
+               "bench_final": {k: final[k] for k in ("value", "ms_per_step")},
+               "bench_under_rocprof_launch_ms": under["roofline"]["launch_ms"]}
+    with open(os.path.join(out, tag + "_pmc.json"), "w") as f:
+        json.dump(summary, f, indent=1)
     print(json.dumps(summary["pmc_mean_per_dispatch"], indent=1))
     secondary(tag, out)
 
