@@ -115,6 +115,17 @@ __global__ void __launch_bounds__(64) dtw_segment_kernel(DtwArgs g) {
     if (PASS == 1 && s == 0 && threadIdx.x == 0 && *g.err != 0) g.path_len[pair] = -1;
 }
 
+// hops + both segment passes of a short pair in one launch (at most sdp::kTailStrips strips: one wave each)
+__global__ void __launch_bounds__(64 * sdp::kTailStrips) dtw_tail_kernel(DtwArgs g) {
+    extern __shared__ __align__(16) unsigned char dtw_smem[];
+    const int pair = blockIdx.x, S = sdp::n_strips(g.M);
+    sdp::path_tail(g.codes + (size_t)pair * sdp::codes_words(g.M, g.N), g.entb + (size_t)pair * S * g.N, g.M, g.N,
+                   g.cross + (size_t)pair * S, g.lens + (size_t)pair * S, g.path + (size_t)pair * (g.M + g.N) * 2,
+                   g.path_len + pair, reinterpret_cast<uint32_t *>(dtw_smem));
+    __syncthreads();
+    if (threadIdx.x == 0 && *g.err != 0) g.path_len[pair] = -1;
+}
+
 __global__ void __launch_bounds__(256) dtw_back_decode_kernel(DtwArgs g) {
     const int pair = blockIdx.z, i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -223,9 +234,13 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
         hipLaunchKernelGGL((dtw_sdp_kernel<3>), dim3(G, B), dim3(64 * NS * 4), smem, s, g);
     }
     RTS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(dtw_hops_kernel, dim3(B), dim3(64), 0, s, g);
-    hipLaunchKernelGGL((dtw_segment_kernel<0>), dim3(strips, B), dim3(64), 0, s, g);
-    hipLaunchKernelGGL((dtw_segment_kernel<1>), dim3(strips, B), dim3(64), 0, s, g);
+    if (strips <= sdp::kTailStrips) {
+        hipLaunchKernelGGL(dtw_tail_kernel, dim3(B), dim3(64 * strips), sdp::tail_lds_bytes(strips), s, g);
+    } else {
+        hipLaunchKernelGGL(dtw_hops_kernel, dim3(B), dim3(64), 0, s, g);
+        hipLaunchKernelGGL((dtw_segment_kernel<0>), dim3(strips, B), dim3(64), 0, s, g);
+        hipLaunchKernelGGL((dtw_segment_kernel<1>), dim3(strips, B), dim3(64), 0, s, g);
+    }
     RTS_HIP(hipGetLastError());
     if (back_dev) {
         hipLaunchKernelGGL(dtw_back_decode_kernel, dim3((N + 255) / 256, M, B), dim3(256), 0, s, g);

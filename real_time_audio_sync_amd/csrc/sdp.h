@@ -810,5 +810,23 @@ __device__ __forceinline__ void path_segment(const uint32_t *codes, int M, int N
     if (total && s == 0 && lane == 0) *total = all;
 }
 
+// The whole backtrack of one problem by one workgroup of n_strips(M) waves (at most kTailStrips): crossings (wave 0),
+// then every wave counts and writes its strip's segment.  For short problems this replaces three launches by one;
+// long ones keep a workgroup per strip (path_hops / path_segment from separate kernels).  `win`: the workgroup's
+// dynamic LDS, 2 * kBtChunks * 64 dwords per wave.
+constexpr int kTailStrips = 16;
+__host__ __device__ inline size_t tail_lds_bytes(int S) { return sizeof(uint32_t) * 2 * kBtChunks * 64 * (size_t)S; }
+__device__ __forceinline__ void path_tail(const uint32_t *codes, const int32_t *entb, int M, int N, int32_t *cross,
+                                          int32_t *lens, int32_t *path, int32_t *total, uint32_t *win) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int S = n_strips(M);
+    uint32_t *mywin = win + (size_t)wave * 2 * kBtChunks * 64;
+    if (wave == 0) path_hops(codes, entb, M, N, cross, mywin);
+    __syncthreads();
+    if (wave < S) path_segment(codes, M, N, wave, cross, lens, 0, path, total, mywin);
+    __syncthreads();
+    if (wave < S) path_segment(codes, M, N, wave, cross, lens, 1, path, total, mywin);
+}
+
 }  // namespace sdp
 }  // namespace rts

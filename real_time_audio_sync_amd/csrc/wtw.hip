@@ -305,6 +305,17 @@ __global__ void __launch_bounds__(64) wtw_big_segment_kernel(WtwArgs g) {
                       g.lens + (size_t)b * S, PASS, g.ws_sub + (size_t)b * 4 * g.W, ctl + 5, win);
 }
 
+// The three kernels above in one launch, for windows of at most sdp::kTailStrips strips (one wave per strip).
+__global__ void __launch_bounds__(64 * sdp::kTailStrips) wtw_big_tail_kernel(WtwArgs g) {
+    extern __shared__ __align__(16) unsigned char wtw_smem[];
+    const int b = blockIdx.x, S = sdp::n_strips(g.W);
+    int32_t *ctl = g.ctl + (size_t)b * 8;
+    if (ctl[0] == 0) return;  // uniform over the workgroup
+    sdp::path_tail(g.codes + (size_t)b * sdp::codes_words(g.W, g.W), g.entb + (size_t)b * S * g.W, ctl[3], ctl[4],
+                   g.cross + (size_t)b * S, g.lens + (size_t)b * S, g.ws_sub + (size_t)b * 4 * g.W, ctl + 5,
+                   reinterpret_cast<uint32_t *>(wtw_smem));
+}
+
 // One workgroup per stream.  If a window is pending (its sub-path was just written by the kernels above): the
 // hand-over (wtw.py:107-128).  Then the column bookkeeping of wtw.py:92-100 in closed
 // form up to the next event: between two windows the stop test (wtw.py:96) sees constant pointers, and a window
@@ -644,9 +655,14 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
                 else
                     hipLaunchKernelGGL((wtw_big_dp_kernel<false, 3>), grid, block, h->smem, s, g);
             }
-            hipLaunchKernelGGL(wtw_big_hops_kernel, dim3(h->B), dim3(64), 0, s, g);
-            hipLaunchKernelGGL((wtw_big_segment_kernel<0>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
-            hipLaunchKernelGGL((wtw_big_segment_kernel<1>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
+            if (sdp::n_strips(h->W) <= sdp::kTailStrips) {
+                hipLaunchKernelGGL(wtw_big_tail_kernel, dim3(h->B), dim3(64 * sdp::n_strips(h->W)),
+                                   sdp::tail_lds_bytes(sdp::n_strips(h->W)), s, g);
+            } else {
+                hipLaunchKernelGGL(wtw_big_hops_kernel, dim3(h->B), dim3(64), 0, s, g);
+                hipLaunchKernelGGL((wtw_big_segment_kernel<0>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
+                hipLaunchKernelGGL((wtw_big_segment_kernel<1>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
+            }
             hipLaunchKernelGGL(wtw_big_ctl_kernel, dim3(h->B), dim3(1024), 0, s, g);
         }
     } else if (h->W > kWtwLdsB) {
