@@ -96,3 +96,20 @@ def check(rc):
     if rc != 0:
         raise RtsyncError("rtsync error %d: %s" % (rc, lib.rts_last_error().decode("utf-8", "replace")))
     return rc
+
+
+def on_device(fn):
+    """Decorator for methods of an object with a ``device`` attribute (a torch.device with an index): run the method
+    with that device current.  A handle belongs to the device it was created on; with several devices driven from
+    one process (shard.ShardedOTW) another one may be current when the call comes."""
+    import functools
+
+    import torch
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kwargs)
+    return wrapped

@@ -46,6 +46,7 @@ class ChromaPlan(object):
     def num_frames(self, n_samples, pad_left):
         return int(nat.lib.rts_chroma_num_frames(int(n_samples), self.fft_len, self.hop, int(pad_left)))
 
+    @nat.on_device
     def frames(self, samples_dev, pad_left, normalize=True, out_dtype=torch.float64, want_stft=False,
                want_chroma=True, n_frames=None):
         """samples_dev: 1-D float32/float64 device tensor.  Returns (chroma [M][12] or None,
@@ -63,6 +64,7 @@ class ChromaPlan(object):
                 self._stream()))
         return chroma, (torch.view_as_complex(stft) if want_stft else None)
 
+    @nat.on_device
     def frames_batch(self, samples_dev, n_samples_dev, n_frames_dev, n_frames_max, pad_left=0, normalize=True,
                      out_dtype=torch.float64):
         """B sample buffers at once: samples_dev [B][stride] float32/64, n_samples_dev / n_frames_dev int32 [B].
@@ -78,6 +80,7 @@ class ChromaPlan(object):
                 self._stream()))
         return out
 
+    @nat.on_device
     def project(self, spec_dev, normalize=True, out_dtype=torch.float64):
         """spec_dev: [M][n_bins] float64 power spectrum on the device -> chroma [M][12]."""
         assert spec_dev.dtype == torch.float64 and spec_dev.is_contiguous() and spec_dev.shape[1] == self.n_bins
@@ -89,6 +92,7 @@ class ChromaPlan(object):
                                                  self._stream()))
         return out
 
+    @nat.on_device
     def diff(self, chroma_dev):
         m = chroma_dev.shape[0]
         out = torch.empty((max(m - 1, 0), 12), dtype=chroma_dev.dtype, device=self.device)

@@ -30,18 +30,7 @@ def frames_tensor(x, device, dtype=None):
     return x.to(device).t().contiguous()
 
 
-def _on_device(fn):
-    """Run a method with the handle's device current (a handle belongs to the device it was created on; with several
-    devices driven from one process -- shard.ShardedOTW -- another one may be current when the call comes)."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapped(self, *args, **kwargs):
-        if torch.cuda.current_device() == self.device.index:
-            return fn(self, *args, **kwargs)
-        with torch.cuda.device(self.device):
-            return fn(self, *args, **kwargs)
-    return wrapped
+_on_device = nat.on_device
 
 
 class BatchedOTW:

@@ -39,9 +39,11 @@ class BatchedWTW(object):
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @nat.on_device
     def reset(self):
         nat.check(nat.lib.rts_wtw_reset(self._h, self._stream()))
 
+    @nat.on_device
     def push(self, cols_dev, n_new_dev=None, precheck=True):
         """cols_dev: [B][n_max][12] float32/float64 device tensor of new live chroma columns."""
         assert cols_dev.is_contiguous() and cols_dev.shape[0] == self.B and cols_dev.shape[2] == 12
@@ -50,9 +52,11 @@ class BatchedWTW(object):
                                        int(cols_dev.shape[1]), n_new_dev.data_ptr() if n_new_dev is not None else None,
                                        int(bool(precheck)), self._stream()))
 
+    @nat.on_device
     def precheck(self):
         nat.check(nat.lib.rts_wtw_push(self._h, None, nat.F64, 0, None, 1, self._stream()))
 
+    @nat.on_device
     def states(self):
         out = np.zeros((self.B, nat.WTW_STATE_LEN), dtype=np.int32)
         nat.check(nat.lib.rts_wtw_read_states(self._h, out.ctypes.data, self._stream()))
@@ -63,6 +67,7 @@ class BatchedWTW(object):
         return dict(chroma_ptr=int(s[0]), live_ptr=int(s[1]), ref_ptr=int(s[2]), status=int(s[3]), n_path=int(s[4]),
                     windows=int(s[5]), cells=(int(np.uint32(s[7])) << 32) | int(np.uint32(s[6])))
 
+    @nat.on_device
     def path(self, b=0):
         n = ctypes.c_int(0)
         nat.check(nat.lib.rts_wtw_read_path(self._h, b, None, 0, ctypes.byref(n), self._stream()))
@@ -71,6 +76,7 @@ class BatchedWTW(object):
             nat.check(nat.lib.rts_wtw_read_path(self._h, b, out.ctypes.data, n.value, ctypes.byref(n), self._stream()))
         return out
 
+    @nat.on_device
     def last_d(self, b=0):
         """The last window's accumulated-cost matrix D (W, W) float64 (needs keep_last_d=True)."""
         out = np.empty((self.W, self.W), dtype=np.float64)
