@@ -71,9 +71,16 @@ struct OtwArgs {
 // and for the 1024-cell window (no ring of either type fits beside its bands).  With float32 features at W <= 512 the
 // ring stays: 4.50 vs 4.62 ms at B = 64, 46.9 vs 48.4 ms at B = 4096 (same-call A/B, one box).
 struct LiveFromGlobal {};
+// The same without a live ring, built for residency (batches of two streams per CU or more): 73 VGPRs instead of
+// 111, so three workgroups share a CU.  What it gives up for that: the helper waves keep one cost cell in flight
+// instead of two, and the chains of the rare steps that are not hits run on wave 2 (idle in such a step) instead of
+// wave 0, whose registers then hold the control state only.  Same arithmetic, same results.
+struct LiveFromGlobalDense {};
 template <typename RT> struct RingElem { using type = RT; };
 template <> struct RingElem<LiveFromGlobal> { using type = float; };
-template <typename RT> constexpr bool kHasLiveRing = !std::is_same<RT, LiveFromGlobal>::value;
+template <> struct RingElem<LiveFromGlobalDense> { using type = float; };
+template <typename RT> constexpr bool kThroughput = std::is_same<RT, LiveFromGlobalDense>::value;
+template <typename RT> constexpr bool kHasLiveRing = !std::is_same<RT, LiveFromGlobal>::value && !kThroughput<RT>;
 
 template <int W, typename RT>
 struct OtwLds {
@@ -90,6 +97,9 @@ struct OtwLds {
     double corner_pa;  // Both step: acc[t-1][jn-1] + 2 d(t, jn), stashed before column jn-1 is overwritten
     double corner_d;   // d(t, jn)
     int cfresh_idx;
+    // row chain wave -> wave 0 (only where the row chain of a step that is not a hit runs on another wave)
+    int rfresh_idx;
+    double rfresh_min;
     // wave 0 -> everyone: the next step.  The pipelined kernel alternates between the two slots, because its hit
     // steps have no barrier between the other waves' read of a plan and wave 0's write of the next one.
     int plan_t[2], plan_j0[2], plan_flags[2];
@@ -969,6 +979,16 @@ __device__ __forceinline__ void otw_cost_row(OtwLds<W, RT> &S, const OtwEnv &e, 
 #pragma unroll
         for (int f = 0; f < kF; f++) lf[f] = (double)S.livew[f][r & (W - 1)];
     }
+    if constexpr (kThroughput<RT>) {  // one cell in flight: registers for residency
+        for (int ka = k_lo + hidx; ka <= k_hi; ka += hn) {
+            double ra[kF];
+            otw_ref_frame(e, ka, ra);
+            const double da = cell_cost(lf, ra, e.euclid);
+            Drow[swz<W>(ka)] = da;
+            if (ka >= dual_lo) S.Dc[ka & 1][swz<W>(r)] = da;
+        }
+        return;
+    }
     for (int ka = k_lo + hidx; ka <= k_hi; ka += 2 * hn) {  // two cells in flight per thread
         const int kb = ka + hn;
         const int kb_c = (kb <= k_hi) ? kb : ka;
@@ -995,6 +1015,16 @@ __device__ __forceinline__ void otw_cost_col(OtwLds<W, RT> &S, const OtwEnv &e, 
     double *Dcol = S.Dc[q & 1];
     double rf[kF];
     otw_ref_frame(e, q, rf);
+    if constexpr (kThroughput<RT>) {
+        for (int ra_ = r_lo + hidx; ra_ <= r_hi; ra_ += hn) {
+            double la[kF];
+            otw_live_frame(e, ra_, la);
+            const double da = cell_cost(la, rf, e.euclid);
+            Dcol[swz<W>(ra_)] = da;
+            if (ra_ >= dual_lo) S.Dr[ra_ & 1][swz<W>(q)] = da;
+        }
+        return;
+    }
     for (int ra_ = r_lo + hidx; ra_ <= r_hi; ra_ += 2 * hn) {
         const int rb_ = ra_ + hn;
         const int rb_c = (rb_ <= r_hi) ? rb_ : ra_;
@@ -1506,7 +1536,25 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 const int jn = j0 + ((pflags & kPlanCol) ? 1 : 0);
                 double *C = (pflags & kPlanCi) ? SP.ShC : S.C, *Csh = (pflags & kPlanCi) ? S.C : SP.ShC;
                 RTS_LW_BEGIN();
-                if (!(pflags & kPlanHit)) __syncthreads();
+                if (!(pflags & kPlanHit)) {
+                    if constexpr (kThroughput<RT>) {
+                        // this step's own strip (the row strip of a Both step), which wave 0 runs in the other flavours
+                        const bool stop2 = (pflags & kPlanStop) != 0;
+                        if (pflags & kPlanRow) {
+                            double rf_min = inf;
+                            int rf_idx = 0x7fffffff;
+                            otw_row_strip<W, DENSE, RT>((pflags & kPlanRi) ? SP.ShR : S.R, a, e, S.Dr[pt & 1], pt, j0, jn, sentinel,
+                                                        rf_min, rf_idx);
+                            if (lane == 0) {
+                                S.rfresh_min = rf_min;
+                                S.rfresh_idx = rf_idx;
+                            }
+                        } else if ((pflags & kPlanCol) && !stop2) {
+                            otw_col_strip<W, DENSE, RT>(S, C, a, e, S.Dc[jn & 1], pt, jn, false, sentinel);
+                        }
+                    }
+                    __syncthreads();
+                }
                 bool drop = false;
                 if ((pflags & (kPlanHit | kPlanRow | kPlanCol)) == (kPlanHit | kPlanRow | kPlanCol)) {
                     // Both step as a hit: the column's last cell (pt-1, jn), as on wave 1
@@ -1557,13 +1605,21 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 } else {
                     double rf_min = inf;
                     int rf_idx = 0x7fffffff;
-                    if (do_row)
-                        otw_row_strip<W, DENSE, RT>(R, a, e, S.Dr[pt & 1], pt, j0, jn, sentinel, rf_min, rf_idx);
-                    else if (do_col && !stop)
-                        otw_col_strip<W, DENSE, RT>(S, C, a, e, S.Dc[jn & 1], pt, jn, false, sentinel);
+                    if constexpr (!kThroughput<RT>) {
+                        if (do_row)
+                            otw_row_strip<W, DENSE, RT>(R, a, e, S.Dr[pt & 1], pt, j0, jn, sentinel, rf_min, rf_idx);
+                        else if (do_col && !stop)
+                            otw_col_strip<W, DENSE, RT>(S, C, a, e, S.Dc[jn & 1], pt, jn, false, sentinel);
+                    }
                     RTS_STAMP(9);
                     __syncthreads();
                     RTS_STAMP(10);
+                    if constexpr (kThroughput<RT>) {  // the row chain ran on wave 2
+                        if (do_row) {
+                            rf_min = rfl(S.rfresh_min);
+                            rf_idx = __builtin_amdgcn_readfirstlane(S.rfresh_idx);
+                        }
+                    }
                     // the three band slots the next hit step's last cell depends on: acc[pt][jn] is what settle() is about
                     // to write, the other two are not touched by it and are read in the same round trip as its inputs
                     const double ld_u = C[swz<W>(pt > 0 ? pt - 1 : 0)], ld_l = R[swz<W>(jn > 0 ? jn - 1 : 0)];
@@ -1910,6 +1966,7 @@ struct rts_otw {
     int spec;           // 1: pipelined kernel (needs 8 waves and no dense mirror); 0: plain kernel
     int device;         // the HIP device the handle's buffers live on (one handle = one device)
     int cus;            // its compute units
+    int tp_from;        // batches of at least tp_from streams per CU take the residency-oriented kernel flavour
     const void *attr_fn[8];  // kernel instantiations whose dynamic-LDS limit is already raised on `device`
     // what the handle has consumed since the last reset, for rts_otw_replay_dense
     int src_kind;       // 0 nothing, 1 the buffers of the last rts_otw_run, 2 the handle-owned history, 3 mixed
@@ -1962,6 +2019,8 @@ static int launch_advance(rts_otw *h, const OtwArgs &args, int B, hipStream_t s)
     const bool f32 = !args.ref_f64 && !args.live_f64;
     if constexpr (NW >= 8) {
         if (args.spec) {
+            // two streams per CU or more: the 73-register flavour, three workgroups per CU
+            if (B >= h->tp_from * h->cus && B > 0) return launch_advance_d<W, NW, false, LiveFromGlobalDense, true>(h, args, B, s);
             if (f32) return launch_advance_d<W, NW, false, float, true>(h, args, B, s);
             // float64 features: the ring (one workgroup per CU at W = 512) while every stream has a CU to itself
             // (B = 64: 4.67 vs 4.93 ms), no ring and up to four workgroups per CU beyond
@@ -2072,6 +2131,8 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
         // tests).  Results are identical.
         const char *sp = getenv("RTS_OTW_SPEC");
         h->spec = sp ? (atoi(sp) != 0) : 1;
+        const char *tp = getenv("RTS_OTW_TP_FROM");  // tests: 0 selects the residency-oriented flavour at any batch size
+        h->tp_from = tp ? atoi(tp) : 2;
     }
     h->live_cap = 2 * N;
     h->path_cap = 3 * N + 8;  // one point per decide(); decides <= row strips + column strips <= 2N + N

@@ -123,6 +123,45 @@ def test_plain_and_pipelined_kernels_agree(gpu, otw_golden, monkeypatch, spec):
         eng.close()
 
 
+def test_residency_flavour_agrees(gpu, otw_golden, monkeypatch):
+    """Batches of more than two streams per CU run a third flavour of the pipelined kernel (no live ring, 73 VGPRs,
+    one cost cell in flight per helper thread, the chains of steps that are not hits on wave 2).  RTS_OTW_TP_FROM=0
+    selects it at any batch size: goldens (every variant, both modes, tie and stop cases) and seeded batches against
+    the oracle, float32 and float64 features, including the 1024-cell window's neighbour c = 500."""
+    monkeypatch.setenv("RTS_OTW_TP_FROM", "0")
+    g = otw_golden
+    ob, synth, oracle = gpu["ob"], gpu["synth"], gpu["oracle"]
+    n = 0
+    for meta in g["cases"]:
+        case = parse_case(meta)
+        if case["c"] > 500:
+            continue  # the 1024-cell window has its own no-ring flavour
+        ref = g[case["group"] + "/ref"].astype(np.float64)
+        live = g[case["group"] + "/live"].astype(np.float64)
+        eng = ob.BatchedOTW(ref, case["c"], case["mrc"], batch=1, variant=case["variant"], euclid=case["euclid"],
+                            dtype=torch.float64)
+        lv, ln = eng.pack([live])
+        eng.run(lv, ln, mode=case["mode"])
+        _check_against_golden(g, case, eng)
+        eng.close()
+        n += 1
+    assert n >= 20
+    for c, n_ref, dt in ((200, 500, torch.float32), (500, 900, torch.float32), (500, 700, torch.float64)):
+        ref, lives = synth.synth_batch(n_ref, 6, seed=1200 + c)
+        lives[2] = lives[2][:, :c + 37]
+        eng = ob.BatchedOTW(ref, c, 3, batch=6, dtype=dt)
+        lv, ln = eng.pack(lives)
+        eng.run(lv, ln)
+        for b, live in enumerate(lives):
+            o = oracle.OtwOracle(ref, c, 3)
+            o.run(live)
+            assert np.array_equal(eng.path(b), o.path), (c, b)
+            rb, cb = eng.bands(b)
+            orb, ocb = o.bands()
+            assert np.array_equal(rb, orb, equal_nan=True) and np.array_equal(cb, ocb, equal_nan=True), (c, b)
+        eng.close()
+
+
 def test_batch_vs_oracle_c500(gpu):
     """Config-3 shaped, scaled down so the dense oracle stays small: 16 different warps of one
     reference, c=500, past the warm-up."""
