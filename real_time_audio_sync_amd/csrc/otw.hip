@@ -418,14 +418,15 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
 #pragma unroll
     for (int m = 1; m < L; m++) lm = vmin(lm, v[m]);
     const double g = wave_min(lm);
-    int cand = 0x7fffffff;
+    int ml = L;  // first cell of this lane that holds the minimum (L: none)
 #pragma unroll
-    for (int m = L - 1; m >= 1; m--) cand = (v[m] == g) ? k1 + L * lane + m : cand;
-    cand = (v0 == g) ? k1 + L * lane : cand;
-    const unsigned long long mask = __ballot(cand != 0x7fffffff);
+    for (int m = L - 1; m >= 1; m--) ml = (v[m] == g) ? m : ml;
+    ml = (v0 == g) ? 0 : ml;
+    const unsigned long long mask = __ballot(ml != L);
     const bool some = (g < inf) && (mask != 0);
+    const int first = (int)__builtin_ctzll(mask | (1ull << 63));  // lanes hold increasing positions
     fmin_out = g;
-    fidx_out = some ? __builtin_amdgcn_readlane(cand, (int)__builtin_ctzll(mask | (1ull << 63))) : 0x7fffffff;
+    fidx_out = some ? k1 + L * first + __builtin_amdgcn_readlane(ml, first) : 0x7fffffff;
 }
 
 // np.argmin over band[lo..hi] (first minimum); (inf, 0x7fffffff) for an empty range.  One wave;
