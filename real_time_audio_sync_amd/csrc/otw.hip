@@ -75,11 +75,11 @@ struct LiveFromGlobal {};
 // 111, so three workgroups share a CU.  What it gives up for that: the helper waves keep one cost cell in flight
 // instead of two, and the chains of the rare steps that are not hits run on wave 2 (idle in such a step) instead of
 // wave 0, whose registers then hold the control state only.  Same arithmetic, same results.
-struct LiveFromGlobalDense {};
+struct LiveFromGlobalLean {};
 template <typename RT> struct RingElem { using type = RT; };
 template <> struct RingElem<LiveFromGlobal> { using type = float; };
-template <> struct RingElem<LiveFromGlobalDense> { using type = float; };
-template <typename RT> constexpr bool kThroughput = std::is_same<RT, LiveFromGlobalDense>::value;
+template <> struct RingElem<LiveFromGlobalLean> { using type = float; };
+template <typename RT> constexpr bool kThroughput = std::is_same<RT, LiveFromGlobalLean>::value;
 template <typename RT> constexpr bool kHasLiveRing = !std::is_same<RT, LiveFromGlobal>::value && !kThroughput<RT>;
 
 template <int W, typename RT>
@@ -2021,7 +2021,7 @@ static int launch_advance(rts_otw *h, const OtwArgs &args, int B, hipStream_t s)
     if constexpr (NW >= 8) {
         if (args.spec) {
             // two streams per CU or more: the 73-register flavour, three workgroups per CU
-            if (B >= h->tp_from * h->cus && B > 0) return launch_advance_d<W, NW, false, LiveFromGlobalDense, true>(h, args, B, s);
+            if (B >= h->tp_from * h->cus && B > 0) return launch_advance_d<W, NW, false, LiveFromGlobalLean, true>(h, args, B, s);
             if (f32) return launch_advance_d<W, NW, false, float, true>(h, args, B, s);
             // float64 features: the ring (one workgroup per CU at W = 512) while every stream has a CU to itself
             // (B = 64: 4.67 vs 4.93 ms), no ring and up to four workgroups per CU beyond
