@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak test (GPU box; the pytest suite runs a shortened form, tests/test_otw_gpu.py): many seeded OTW / LiveNote / LiveNoteV2 configurations with the
-band widths that use the 128-, 256- and 512-cell windows, run through the library's default (pipelined) kernel and
+band widths that use the 128-, 256-, 512- and 1024-cell windows, run through the library's default (pipelined) kernel and
 compared bit for bit with the dense CPU oracle -- path, end state, both bands.
 
     python3 tests/otw_soak.py [n_trials] [seed]
@@ -24,7 +24,7 @@ def run(n_trials=120, seed=7, verbose=True):
     t0 = time.time()
     checked = 0
     for trial in range(n_trials):
-        c = int(rs.choice([53, 60, 64, 100, 116, 117, 130, 200, 244, 245, 300, 400, 500]))
+        c = int(rs.choice([53, 60, 64, 100, 116, 117, 130, 200, 244, 245, 300, 400, 500, 500, 501, 640, 1012]))
         n_ref = int(rs.choice([c // 2 + 3, c + 1, c + 40, 2 * c, 3 * c]))
         n_ref = min(n_ref, 1400)
         mrc = int(rs.choice([1, 2, 3, 5]))
