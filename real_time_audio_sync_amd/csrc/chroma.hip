@@ -650,6 +650,7 @@ struct rts_chroma {
     double *fbt;       // device [L/2+1][12]
     size_t smem_frames, smem_frames4096, smem_project;
     int device;  // the HIP device the plan's tables live on
+    int cus;     // its compute units
 };
 
 static int chroma_check_device(const rts_chroma *h) {
@@ -691,7 +692,8 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
     if (!h) return set_error(RTS_ERR_INVALID, "out of host memory");
     h->L = fft_len;
     h->hop = hop;
-    if (hipGetDevice(&h->device) != hipSuccess) {
+    if (hipGetDevice(&h->device) != hipSuccess ||
+        hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->cus < 1) {
         free(h);
         return set_error(RTS_ERR_HIP, "hipGetDevice failed");
     }
@@ -794,7 +796,9 @@ int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, 
     g.samples_f64 = sample_dtype == RTS_F64;
     g.out_f64 = out_dtype == RTS_F64;
     const int groups = (n_frames + kChromaFR - 1) / kChromaFR;
-    const int grid = groups < 1024 ? groups : 1024;
+    // one workgroup per CU (155 KB of LDS each) walking its share of the frame groups: 41.7 M frames/s against 40.7 M
+    // with four short-lived workgroups per CU (each one loads the twiddle table and its window registers first)
+    const int grid = groups < h->cus ? groups : h->cus;
     // fft_len 4096 with 32-bit sample indices: the specialised kernel; anything else: the generic one
     const bool fast = (h->L == 4096) && (n_samples + 2LL * h->L + (long long)n_frames * h->hop < 0x7fffffffLL);
     if (fast) {
