@@ -57,6 +57,7 @@ struct WtwArgs {
     int32_t *err;
     int n_rg, n_strips_wg;
     int M, N, W, hopf, path_cap;
+    int fill_separate;         // long windows: the hand-over's fill and column records by wtw_big_fill_kernel
 };
 
 __device__ __forceinline__ double wtw_dot_chain(const double *x, const double *y) {
@@ -316,6 +317,27 @@ __global__ void __launch_bounds__(64 * sdp::kTailStrips) wtw_big_tail_kernel(Wtw
                    reinterpret_cast<uint32_t *>(wtw_smem));
 }
 
+// Hands a window to the DP launch that follows: its boundary words start as "not written", and its reference columns
+// become float64 records with their norms.  `tid` of `nt` threads share the work.
+__device__ __forceinline__ void wtw_window_handover(const WtwArgs &g, int b, int ref_ptr, int nm, size_t tid, size_t nt) {
+    const int W = g.W;
+    unsigned long long *bnd = g.bnd + (size_t)b * sdp::n_strips(W) * W;
+    const size_t words = (size_t)(g.n_rg > 1 ? g.n_rg - 1 : 0) * nm;
+    for (size_t k = tid; k < words; k += nt) bnd[k] = sdp::kSentinel;
+    for (size_t col = tid; col < (size_t)nm; col += nt)
+        sdp::prep_column<sdp::WtwPolicy>(g.ref, 1, (long long)ref_ptr + (long long)col,
+                                         g.yrec + (size_t)b * W * sdp::kYRec - (size_t)ref_ptr * sdp::kYRec);
+}
+
+// Long windows (W = 10 000: 12.5 MB of boundary words): the hand-over by many workgroups instead of the control
+// kernel's one -- after it, reading the window it has just announced in ctl[].
+__global__ void __launch_bounds__(256) wtw_big_fill_kernel(WtwArgs g) {
+    const int b = blockIdx.y;
+    const int32_t *ctl = g.ctl + (size_t)b * 8;
+    if (ctl[0] == 0) return;
+    wtw_window_handover(g, b, ctl[2], ctl[4], (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+
 // One workgroup per stream.  If a window is pending (its sub-path was just written by the kernels above): the
 // hand-over (wtw.py:107-128).  Then the column bookkeeping of wtw.py:92-100 in closed
 // form up to the next event: between two windows the stop test (wtw.py:96) sees constant pointers, and a window
@@ -386,14 +408,7 @@ __global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) {
         }
     }
     if (!next_pending && status == RTS_RUNNING && chroma_ptr >= g.N && appended_raw > g.N) status = RTS_LIVE_OVERFLOW;
-    if (next_pending) {  // hand the window to the DP launch that follows; its boundary words start as "not written"
-        unsigned long long *bnd = g.bnd + (size_t)b * sdp::n_strips(W) * W;
-        const size_t words = (size_t)(g.n_rg > 1 ? g.n_rg - 1 : 0) * nm;
-        for (size_t k = tid; k < words; k += NT) bnd[k] = sdp::kSentinel;
-        for (int col = tid; col < nm; col += NT)  // the window's reference columns as float64 records with their norms
-            sdp::prep_column<sdp::WtwPolicy>(g.ref, 1, (long long)ref_ptr + col,
-                                             g.yrec + (size_t)b * W * sdp::kYRec - (size_t)ref_ptr * sdp::kYRec);
-    }
+    if (next_pending && !g.fill_separate) wtw_window_handover(g, b, ref_ptr, nm, tid, NT);
     __syncthreads();
     if (tid == 0) {
         st[0] = chroma_ptr;
@@ -631,6 +646,7 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.yrec = h->yrec;
     g.err = h->err;
     g.n_rg = h->n_rg;
+    g.fill_separate = ((size_t)(h->n_rg > 1 ? h->n_rg - 1 : 0) * h->W > (1u << 16)) ? 1 : 0;  // more than 0.5 MB of boundary words
     g.n_strips_wg = h->big_waves;
     g.M = h->M;
     g.N = h->N;
@@ -642,6 +658,7 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
         // further one dtw_hop / hop more (the live pointer advances by exactly that per window, wtw.py:118-128)
         const int rounds = n_max / h->hopf + 1;
         hipLaunchKernelGGL(wtw_big_ctl_kernel, dim3(h->B), dim3(1024), 0, s, g);
+        if (g.fill_separate) hipLaunchKernelGGL(wtw_big_fill_kernel, dim3(128, h->B), dim3(256), 0, s, g);
         for (int r = 0; r < rounds; r++) {
             const dim3 grid(h->big_grid, h->B), block(64 * h->big_waves * (1 + h->big_helpers));
             if (h->big_helpers == 2) {
@@ -664,6 +681,7 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
                 hipLaunchKernelGGL((wtw_big_segment_kernel<1>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
             }
             hipLaunchKernelGGL(wtw_big_ctl_kernel, dim3(h->B), dim3(1024), 0, s, g);
+            if (g.fill_separate) hipLaunchKernelGGL(wtw_big_fill_kernel, dim3(128, h->B), dim3(256), 0, s, g);
         }
     } else if (h->W > kWtwLdsB) {
         hipLaunchKernelGGL((wtw_advance_kernel<false>), dim3(h->B), dim3(kWtwNT), h->smem, s, g);
