@@ -509,7 +509,10 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
                 //      (16 mf + q for "up", one less for "diagonal" = what lane 0 received as ent_up one step earlier)
                 if (HIDX == 0 && mf >= 0 && mf < nch) {
                     const uint32_t cw = codes_l[(mf & 1) * 64 + lane];
-                    int ecollect = 0;  // lane q: the entry column of lane 63 at step q (bottom row, column 16 mf + q - 63)
+                    // the strip's exit row: its bottom row, or the matrix's last row in the last strip -- so that the
+                    // backtrack can hop over the last strip like over every other one instead of walking it first
+                    const int exit_lane = (strip * 64 + 63 < M) ? 63 : (M - 1) & 63;
+                    int ecollect = 0;  // lane q: the entry column of the exit row at step q (column 16 mf + q - exit_lane)
                     static_for<0, kChunk>([&](auto qc) {
                         constexpr int q = decltype(qc)::value;
                         // code bits as lane masks (kLeft = 00, kUp = 01, kDiag = 10): bit-selects instead of
@@ -521,11 +524,11 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
                         const int m_ab = m_up | m_dg;
                         ent = (from_above & m_ab) | (ent & ~m_ab);
                         ent_upprev = ent_up;
-                        const int el = __builtin_amdgcn_readlane(ent, 63);
+                        const int el = __builtin_amdgcn_readlane(ent, exit_lane);
                         int &ec = ecollect;  // (an asm operand alone does not make the generic lambda capture it)
                         asm("v_writelane_b32 %0, %1, %2" : "+v"(ec) : "s"(el), "n"(q));
                     });
-                    const int col = kChunk * mf - 63 + lane;
+                    const int col = kChunk * mf - exit_lane + lane;
                     if (lane < kChunk && col >= 0 && col < N) pb.entb[(size_t)strip * N + col] = ecollect;
                 }
                 if (pre) commit_records(mh + 1);
@@ -768,18 +771,19 @@ __device__ __forceinline__ int walk_strip(const uint32_t *codes, int N, int &i, 
 }
 
 // One wave: cross[s] = column at which the path crosses the bottom row of strip s (s < S - 1), cross[S-1] = N - 1.
+// entb[s][j] is the column at which the best path of (exit row of strip s, column j) came in from the row above the
+// strip (the exit row is the bottom row, or the matrix's last row in the last strip), so the crossings follow from one
+// dependent load per strip and no strip has to be walked.
 __device__ __forceinline__ void path_hops(const uint32_t *codes, const int32_t *entb, int M, int N, int32_t *cross,
                                           uint32_t *win) {
     const int lane = threadIdx.x & 63;
     const int S = n_strips(M);
-    int i = M - 1, j = N - 1;
+    int j = N - 1;
     if (lane == 0) cross[S - 1] = j;
-    if (S == 1) return;
-    walk_strip(codes, N, i, j, nullptr, 0, win);  // leaves the last strip at (64 (S-1) - 1, j)
-    for (int s = S - 2; s >= 0; s--) {
-        if (lane == 0) cross[s] = j;
-        if (s > 0) j = entb[(size_t)s * N + j];  // uniform load; one dependent round trip per strip
+    for (int s = S - 1; s >= 1; s--) {
+        j = entb[(size_t)s * N + j];  // uniform load; one dependent round trip per strip
         j = j < 0 ? 0 : (j >= N ? N - 1 : j);
+        if (lane == 0) cross[s - 1] = j;
     }
 }
 
