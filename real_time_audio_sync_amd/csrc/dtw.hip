@@ -36,6 +36,7 @@ struct DtwArgs {
     unsigned long long *bnd;   // [B][n_strips][N]
     int32_t *entb;             // [B][n_strips][N]
     int32_t *cross, *lens;     // [B][n_strips]
+    int32_t *pscr;             // [B][scratch_pairs(M, N)][2] path segments as walked (sdp::path_segment)
     double *yrec;              // [B][N][14] prepared column records
     int32_t *err;
     int n_rg, n_strips_wg;
@@ -111,7 +112,8 @@ __global__ void __launch_bounds__(64) dtw_segment_kernel(DtwArgs g) {
     const int pair = blockIdx.y, s = blockIdx.x, S = sdp::n_strips(g.M);
     int32_t *path = g.path + (size_t)pair * (g.M + g.N) * 2;
     sdp::path_segment(g.codes + (size_t)pair * sdp::codes_words(g.M, g.N), g.M, g.N, s, g.cross + (size_t)pair * S,
-                      g.lens + (size_t)pair * S, PASS, path, g.path_len + pair, win);
+                      g.lens + (size_t)pair * S, PASS, path, g.path_len + pair, win,
+                      g.pscr + (size_t)pair * 2 * sdp::scratch_pairs(g.M, g.N));
     if (PASS == 1 && s == 0 && threadIdx.x == 0 && *g.err != 0) g.path_len[pair] = -1;
 }
 
@@ -121,7 +123,8 @@ __global__ void __launch_bounds__(64 * sdp::kTailStrips) dtw_tail_kernel(DtwArgs
     const int pair = blockIdx.x, S = sdp::n_strips(g.M);
     sdp::path_tail(g.codes + (size_t)pair * sdp::codes_words(g.M, g.N), g.entb + (size_t)pair * S * g.N, g.M, g.N,
                    g.cross + (size_t)pair * S, g.lens + (size_t)pair * S, g.path + (size_t)pair * (g.M + g.N) * 2,
-                   g.path_len + pair, reinterpret_cast<uint32_t *>(dtw_smem));
+                   g.path_len + pair, reinterpret_cast<uint32_t *>(dtw_smem),
+                   g.pscr + (size_t)pair * 2 * sdp::scratch_pairs(g.M, g.N));
     __syncthreads();
     if (threadIdx.x == 0 && *g.err != 0) g.path_len[pair] = -1;
 }
@@ -149,7 +152,8 @@ int rts_dtw_workspace_bytes(int M, int N, int B, size_t *bytes) {
     const size_t strips = (size_t)B * sdp::n_strips(M);
     *bytes = 256 + align256(sizeof(unsigned long long) * strips * N) + align256(sizeof(int32_t) * strips * N) +
              2 * align256(sizeof(int32_t) * strips) + align256(sizeof(double) * (size_t)B * N * sdp::kYRec) +
-             align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N));
+             align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N)) +
+             align256(sizeof(int32_t) * 2 * (size_t)B * sdp::scratch_pairs(M, N));
     return RTS_OK;
 }
 
@@ -205,6 +209,8 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
         g.yrec = reinterpret_cast<double *>(p);
         p += align256(sizeof(double) * (size_t)B * N * sdp::kYRec);
         g.codes = reinterpret_cast<uint32_t *>(p);
+        p += align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N));
+        g.pscr = reinterpret_cast<int32_t *>(p);
     }
     g.n_rg = n_rg;
     g.n_strips_wg = NS;

@@ -691,11 +691,11 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
 // the left is fetched into registers while the current one is being walked.
 constexpr int kBtChunks = 8;
 
-// Walks from (i, j) while the position stays inside strip (i >> 6) and has not reached (0, 0).  Visited points
-// (the start included, the first point outside the strip excluded) are written to out[2 * (out_last - k)] for the
-// k-th visited point when `out` is not null.  Returns the number of visited points; (i, j) is left at the first
+// Walks from (i, j) while the position stays inside strip (i >> 6) and has not reached (0, 0).  The k-th visited point
+// (the start included, the first point outside the strip excluded) is written to out[2 * (out_base + k)] when `out` is
+// not null -- in walk order, i.e. the path backwards.  Returns the number of visited points; (i, j) is left at the first
 // position outside the strip (or at (0, 0), which counts as visited).
-__device__ __forceinline__ int walk_strip(const uint32_t *codes, int N, int &i, int &j, int32_t *out, int out_last,
+__device__ __forceinline__ int walk_strip(const uint32_t *codes, int N, int &i, int &j, int32_t *out, int out_base,
                                           uint32_t *win) {
     const int lane = threadIdx.x & 63;
     const int nch = n_chunks(N);
@@ -735,7 +735,7 @@ __device__ __forceinline__ int walk_strip(const uint32_t *codes, int N, int &i, 
         uint32_t nxt = (c0 - 1 >= wlo) ? win[(buf * kBtChunks + (c0 - 1 - wlo)) * 64 + lane] : 0u;
         for (;;) {
             // the current position is inside the strip: visit it
-            if (out && lane == 0) *reinterpret_cast<int2 *>(out + 2 * (size_t)(out_last - n)) = make_int2(i, j);
+            if (out && lane == 0) *reinterpret_cast<int2 *>(out + 2 * (size_t)(out_base + n)) = make_int2(i, j);
             n++;
             if (i == 0 && j == 0) {
                 inside = false;
@@ -787,15 +787,21 @@ __device__ __forceinline__ void path_hops(const uint32_t *codes, const int32_t *
     }
 }
 
-// The segment of strip s: start point and walk.  pass 0: lens[s] = number of points.  pass 1: writes the points to
-// path[] (forward order) using the lens of all strips; *total (if not null, strip 0 only) receives the path length.
+// The segment of strip s.  pass 0: one walk, which parks the segment's points -- backwards, as walked -- in `scratch` at
+// pair 64 s + (column at which the path enters the strip) and leaves their number in lens[s]; the parking places of
+// different strips cannot overlap (a segment has at most 64 + cross[s] - cross[s-1] points), and 64 n_strips + N pairs
+// hold them all.  pass 1: with the lens of all strips known, a coalesced copy to the segment's place in path[] in
+// forward order; *total (if not null, strip 0 only) receives the path length.
+__host__ __device__ inline size_t scratch_pairs(int M, int N) { return (size_t)64 * n_strips(M) + N; }
 __device__ __forceinline__ void path_segment(const uint32_t *codes, int M, int N, int s, const int32_t *cross,
-                                             int32_t *lens, int pass, int32_t *path, int32_t *total, uint32_t *win) {
+                                             int32_t *lens, int pass, int32_t *path, int32_t *total, uint32_t *win,
+                                             int32_t *scratch) {
     const int lane = threadIdx.x & 63;
     const int S = n_strips(M);
-    int i = (s == S - 1) ? M - 1 : 64 * s + 63, j = cross[s];
+    const int park = 64 * s + (s > 0 ? cross[s - 1] : 0);
     if (pass == 0) {
-        const int n = walk_strip(codes, N, i, j, nullptr, 0, win);
+        int i = (s == S - 1) ? M - 1 : 64 * s + 63, j = cross[s];
+        const int n = walk_strip(codes, N, i, j, scratch, park, win);
         if (lane == 0) lens[s] = n;
         return;
     }
@@ -810,7 +816,9 @@ __device__ __forceinline__ void path_segment(const uint32_t *codes, int M, int N
         all += __shfl_xor(all, d);
     }
     const int n = lens[s];
-    walk_strip(codes, N, i, j, path, off + n - 1, win);
+    const int2 *src = reinterpret_cast<const int2 *>(scratch) + park;
+    int2 *dst = reinterpret_cast<int2 *>(path) + off;
+    for (int q = lane; q < n; q += 64) dst[n - 1 - q] = src[q];
     if (total && s == 0 && lane == 0) *total = all;
 }
 
@@ -821,15 +829,15 @@ __device__ __forceinline__ void path_segment(const uint32_t *codes, int M, int N
 constexpr int kTailStrips = 16;
 __host__ __device__ inline size_t tail_lds_bytes(int S) { return sizeof(uint32_t) * 2 * kBtChunks * 64 * (size_t)S; }
 __device__ __forceinline__ void path_tail(const uint32_t *codes, const int32_t *entb, int M, int N, int32_t *cross,
-                                          int32_t *lens, int32_t *path, int32_t *total, uint32_t *win) {
+                                          int32_t *lens, int32_t *path, int32_t *total, uint32_t *win, int32_t *scratch) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int S = n_strips(M);
     uint32_t *mywin = win + (size_t)wave * 2 * kBtChunks * 64;
     if (wave == 0) path_hops(codes, entb, M, N, cross, mywin);
     __syncthreads();
-    if (wave < S) path_segment(codes, M, N, wave, cross, lens, 0, path, total, mywin);
+    if (wave < S) path_segment(codes, M, N, wave, cross, lens, 0, path, total, mywin, scratch);
     __syncthreads();
-    if (wave < S) path_segment(codes, M, N, wave, cross, lens, 1, path, total, mywin);
+    if (wave < S) path_segment(codes, M, N, wave, cross, lens, 1, path, total, mywin, scratch);
 }
 
 }  // namespace sdp

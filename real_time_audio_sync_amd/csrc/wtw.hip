@@ -48,6 +48,7 @@ struct WtwArgs {
     double *dlast;        // [B][W][W] last window's D (optional, NULL = not stored)
     // W > kWtwLdsW (strip DP):
     int32_t *ws_sub;           // [B][4W] ints: the window's sub-path, reversed
+    int32_t *ws_scr;           // [B][scratch_pairs(W, W)][2]: its segments as walked (sdp::path_segment)
     int32_t *ctl;              // [B][8]: pending, live_ptr, ref_ptr, n, m of the window being computed
     uint32_t *codes;           // [B][codes_words(W, W)] packed step codes
     unsigned long long *bnd;   // [B][n_strips(W)][W] rows handed between row groups
@@ -303,7 +304,8 @@ __global__ void __launch_bounds__(64) wtw_big_segment_kernel(WtwArgs g) {
     int32_t *ctl = g.ctl + (size_t)b * 8;
     if (ctl[0] == 0 || s >= sdp::n_strips(ctl[3])) return;
     sdp::path_segment(g.codes + (size_t)b * sdp::codes_words(g.W, g.W), ctl[3], ctl[4], s, g.cross + (size_t)b * S,
-                      g.lens + (size_t)b * S, PASS, g.ws_sub + (size_t)b * 4 * g.W, ctl + 5, win);
+                      g.lens + (size_t)b * S, PASS, g.ws_sub + (size_t)b * 4 * g.W, ctl + 5, win,
+                      g.ws_scr + (size_t)b * 2 * sdp::scratch_pairs(g.W, g.W));
 }
 
 // The three kernels above in one launch, for windows of at most sdp::kTailStrips strips (one wave per strip).
@@ -314,7 +316,7 @@ __global__ void __launch_bounds__(64 * sdp::kTailStrips) wtw_big_tail_kernel(Wtw
     if (ctl[0] == 0) return;  // uniform over the workgroup
     sdp::path_tail(g.codes + (size_t)b * sdp::codes_words(g.W, g.W), g.entb + (size_t)b * S * g.W, ctl[3], ctl[4],
                    g.cross + (size_t)b * S, g.lens + (size_t)b * S, g.ws_sub + (size_t)b * 4 * g.W, ctl + 5,
-                   reinterpret_cast<uint32_t *>(wtw_smem));
+                   reinterpret_cast<uint32_t *>(wtw_smem), g.ws_scr + (size_t)b * 2 * sdp::scratch_pairs(g.W, g.W));
 }
 
 // Hands a window to the DP launch that follows: its boundary words start as "not written", and its reference columns
@@ -470,7 +472,7 @@ struct rts_wtw {
     int32_t *appended, *state, *path;
     int8_t *bwork;
     double *dlast;
-    int32_t *ws_sub, *ctl, *err, *entb, *cross, *lens;
+    int32_t *ws_sub, *ws_scr, *ctl, *err, *entb, *cross, *lens;
     double *yrec;
     uint32_t *codes;
     unsigned long long *bnd;
@@ -534,6 +536,7 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         (e = hipMalloc((void **)&h->path, sizeof(int32_t) * 2 * (size_t)h->path_cap * B)) != hipSuccess ||
         (!big && W > kWtwLdsB && (e = hipMalloc((void **)&h->bwork, (size_t)B * W * W)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->ws_sub, sizeof(int32_t) * 4 * (size_t)W * B)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->ws_scr, sizeof(int32_t) * 2 * sdp::scratch_pairs(W, W) * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->ctl, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->err, 16)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->codes, sizeof(uint32_t) * sdp::codes_words(W, W) * B)) != hipSuccess) ||
@@ -580,6 +583,7 @@ int rts_wtw_destroy(rts_wtw *h) {
     if (h->bwork) (void)hipFree(h->bwork);
     if (h->dlast) (void)hipFree(h->dlast);
     if (h->ws_sub) (void)hipFree(h->ws_sub);
+    if (h->ws_scr) (void)hipFree(h->ws_scr);
     if (h->ctl) (void)hipFree(h->ctl);
     if (h->err) (void)hipFree(h->err);
     if (h->codes) (void)hipFree(h->codes);
@@ -637,6 +641,7 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.bwork = h->bwork;
     g.dlast = h->dlast;
     g.ws_sub = h->ws_sub;
+    g.ws_scr = h->ws_scr;
     g.ctl = h->ctl;
     g.codes = h->codes;
     g.bnd = h->bnd;
