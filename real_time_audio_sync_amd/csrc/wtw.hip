@@ -308,17 +308,6 @@ __global__ void __launch_bounds__(64) wtw_big_segment_kernel(WtwArgs g) {
                       g.ws_scr + (size_t)b * 2 * sdp::scratch_pairs(g.W, g.W));
 }
 
-// The three kernels above in one launch, for windows of at most sdp::kTailStrips strips (one wave per strip).
-__global__ void __launch_bounds__(64 * sdp::kTailStrips) wtw_big_tail_kernel(WtwArgs g) {
-    extern __shared__ __align__(16) unsigned char wtw_smem[];
-    const int b = blockIdx.x, S = sdp::n_strips(g.W);
-    int32_t *ctl = g.ctl + (size_t)b * 8;
-    if (ctl[0] == 0) return;  // uniform over the workgroup
-    sdp::path_tail(g.codes + (size_t)b * sdp::codes_words(g.W, g.W), g.entb + (size_t)b * S * g.W, ctl[3], ctl[4],
-                   g.cross + (size_t)b * S, g.lens + (size_t)b * S, g.ws_sub + (size_t)b * 4 * g.W, ctl + 5,
-                   reinterpret_cast<uint32_t *>(wtw_smem), g.ws_scr + (size_t)b * 2 * sdp::scratch_pairs(g.W, g.W));
-}
-
 // Hands a window to the DP launch that follows: its boundary words start as "not written", and its reference columns
 // become float64 records with their norms.  `tid` of `nt` threads share the work.
 __device__ __forceinline__ void wtw_window_handover(const WtwArgs &g, int b, int ref_ptr, int nm, size_t tid, size_t nt) {
@@ -344,7 +333,7 @@ __global__ void __launch_bounds__(256) wtw_big_fill_kernel(WtwArgs g) {
 // hand-over (wtw.py:107-128).  Then the column bookkeeping of wtw.py:92-100 in closed
 // form up to the next event: between two windows the stop test (wtw.py:96) sees constant pointers, and a window
 // fires exactly when chroma_ptr reaches live_ptr + W.
-__global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) {
+__device__ __forceinline__ void wtw_ctl_body(const WtwArgs &g) {
     __shared__ int s_cnt;
     const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int W = g.W;
@@ -361,7 +350,8 @@ __global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) {
     if (pending) {
         // sub[] holds the path from (0, 0) to (n-1, m-1); l is non-decreasing along it, so the points handed over
         // (l <= dtw_hop / hop, wtw.py:113) are a prefix of it
-        int len = ctl[5];
+        // (written by another wave of this workgroup when the backtrack ran in the same launch: not through L1)
+        int len = __hip_atomic_load(ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         len = len < 1 ? 1 : (len > 2 * W ? 2 * W : len);
         int local = 0;
         for (int q = tid; q < len; q += NT) local += (sub[2 * q] <= g.hopf) ? 1 : 0;
@@ -427,6 +417,21 @@ __global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) {
         ctl[3] = nn;
         ctl[4] = nm;
     }
+}
+
+__global__ void __launch_bounds__(1024) wtw_big_ctl_kernel(WtwArgs g) { wtw_ctl_body(g); }
+
+// Backtrack (if a window is pending) and control step in one launch, for windows of at most sdp::kTailStrips strips.
+__global__ void __launch_bounds__(64 * sdp::kTailStrips) wtw_big_tail_ctl_kernel(WtwArgs g) {
+    extern __shared__ __align__(16) unsigned char wtw_smem[];
+    const int b = blockIdx.x, S = sdp::n_strips(g.W);
+    int32_t *ctl = g.ctl + (size_t)b * 8;
+    if (ctl[0] != 0)  // uniform over the workgroup
+        sdp::path_tail(g.codes + (size_t)b * sdp::codes_words(g.W, g.W), g.entb + (size_t)b * S * g.W, ctl[3], ctl[4],
+                       g.cross + (size_t)b * S, g.lens + (size_t)b * S, g.ws_sub + (size_t)b * 4 * g.W, ctl + 5,
+                       reinterpret_cast<uint32_t *>(wtw_smem), g.ws_scr + (size_t)b * 2 * sdp::scratch_pairs(g.W, g.W));
+    __syncthreads();
+    wtw_ctl_body(g);
 }
 
 // wtw.py:76-77: the check made at the top of insert(), before any column is processed.
@@ -678,14 +683,14 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
                     hipLaunchKernelGGL((wtw_big_dp_kernel<false, 3>), grid, block, h->smem, s, g);
             }
             if (sdp::n_strips(h->W) <= sdp::kTailStrips) {
-                hipLaunchKernelGGL(wtw_big_tail_kernel, dim3(h->B), dim3(64 * sdp::n_strips(h->W)),
+                hipLaunchKernelGGL(wtw_big_tail_ctl_kernel, dim3(h->B), dim3(64 * sdp::n_strips(h->W)),
                                    sdp::tail_lds_bytes(sdp::n_strips(h->W)), s, g);
             } else {
                 hipLaunchKernelGGL(wtw_big_hops_kernel, dim3(h->B), dim3(64), 0, s, g);
                 hipLaunchKernelGGL((wtw_big_segment_kernel<0>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
                 hipLaunchKernelGGL((wtw_big_segment_kernel<1>), dim3(sdp::n_strips(h->W), h->B), dim3(64), 0, s, g);
+                hipLaunchKernelGGL(wtw_big_ctl_kernel, dim3(h->B), dim3(1024), 0, s, g);
             }
-            hipLaunchKernelGGL(wtw_big_ctl_kernel, dim3(h->B), dim3(1024), 0, s, g);
             if (g.fill_separate) hipLaunchKernelGGL(wtw_big_fill_kernel, dim3(128, h->B), dim3(256), 0, s, g);
         }
     } else if (h->W > kWtwLdsB) {
