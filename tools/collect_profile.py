@@ -128,7 +128,7 @@ def secondary(tag, out):
         f.write("".join(l + "\n" for l in p.stdout.splitlines() if l.startswith("{")))
     stats = find(d, "kernel_stats.csv")
     keep = ("sdp_kernel", "big_dp", "big_ctl", "big_hops", "big_segment", "dtw_hops", "dtw_segment", "dtw_cost", "dtw_prep",
-            "chroma_frames", "wtw_advance", "_tail_kernel")
+            "chroma_frames", "wtw_advance", "_tail_kernel", "tail_ctl", "big_fill")
     with open(stats) as f, open(os.path.join(out, tag + "_sdp_kernel_stats.csv"), "w") as g:
         for i, line in enumerate(f):
             if i == 0 or any(k in line for k in keep):
