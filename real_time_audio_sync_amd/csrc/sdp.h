@@ -826,7 +826,7 @@ __device__ __forceinline__ void path_segment(const uint32_t *codes, int M, int N
 // then every wave counts and writes its strip's segment.  For short problems this replaces three launches by one;
 // long ones keep a workgroup per strip (path_hops / path_segment from separate kernels).  `win`: the workgroup's
 // dynamic LDS, 2 * kBtChunks * 64 dwords per wave.
-constexpr int kTailStrips = 16;
+constexpr int kTailStrips = 12;  // 48 KB of dynamic LDS: below the 64 KB a launch gets without an attribute, static LDS included
 __host__ __device__ inline size_t tail_lds_bytes(int S) { return sizeof(uint32_t) * 2 * kBtChunks * 64 * (size_t)S; }
 __device__ __forceinline__ void path_tail(const uint32_t *codes, const int32_t *entb, int M, int N, int32_t *cross,
                                           int32_t *lens, int32_t *path, int32_t *total, uint32_t *win, int32_t *scratch) {

@@ -58,7 +58,8 @@ def test_dtw_batch_shapes_and_backpointers():
         assert np.array_equal(acc[k].cpu().numpy(), oacc), k
 
 
-@pytest.mark.parametrize("M,N", [(1, 1), (1, 7), (9, 1), (2, 2), (513, 40), (1100, 90)])
+# 768 / 769 rows: 12 strips (whole backtrack in one launch) / 13 strips (a workgroup per strip)
+@pytest.mark.parametrize("M,N", [(1, 1), (1, 7), (9, 1), (2, 2), (513, 40), (1100, 90), (768, 130), (769, 130), (64, 700)])
 def test_dtw_edge_shapes(M, N):
     import oracle
     from real_time_audio_sync_amd import synth

@@ -87,7 +87,8 @@ def test_batched_streams_vs_oracle():
         eng.close()
 
 
-@pytest.mark.parametrize("W,hopf,n_ref", [(700, 350, 2500), (2000, 1000, 5000)])
+# 768 / 800 frames: 12 strips (backtrack and control step in one launch) / 13 strips (separate kernels)
+@pytest.mark.parametrize("W,hopf,n_ref", [(700, 350, 2500), (2000, 1000, 5000), (768, 300, 2600), (800, 410, 2700)])
 def test_large_windows_hbm_resident(W, hopf, n_ref):
     """Windows beyond the 512 frames that fit LDS run from an HBM workspace; results stay bit-exact."""
     import oracle
