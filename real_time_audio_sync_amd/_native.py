@@ -98,6 +98,20 @@ def check(rc):
     return rc
 
 
+def destroy_on(device, destroy_fn, handle):
+    """Free a handle's device buffers with the handle's own device current (hipFree of a foreign device's pointer
+    from another current device is an error the destroy functions cannot report)."""
+    import torch
+    try:
+        if device.index is None or torch.cuda.current_device() == device.index:
+            destroy_fn(handle)
+        else:
+            with torch.cuda.device(device):
+                destroy_fn(handle)
+    except Exception:   # interpreter shutdown: torch may already be gone; the process is ending anyway
+        pass
+
+
 def on_device(fn):
     """Decorator for methods of an object with a ``device`` attribute (a torch.device with an index): run the method
     with that device current.  A handle belongs to the device it was created on; with several devices driven from

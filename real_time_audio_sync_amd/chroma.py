@@ -36,7 +36,7 @@ class ChromaPlan(object):
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            nat.lib.rts_chroma_destroy(h)
+            nat.destroy_on(self.device, nat.lib.rts_chroma_destroy, h)
 
     __del__ = close
 

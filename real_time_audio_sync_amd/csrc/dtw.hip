@@ -39,6 +39,7 @@ struct DtwArgs {
     int32_t *pscr;             // [B][scratch_pairs(M, N)][2] path segments as walked (sdp::path_segment)
     double *yrec;              // [B][N][14] prepared column records
     int32_t *err;
+    int32_t *ticket;           // [B] next row group of each pair (sdp::for_each_rowgroup)
     int n_rg, n_strips_wg;
 };
 
@@ -95,8 +96,9 @@ __global__ void __launch_bounds__(H == 2 ? 384 : 256) dtw_sdp_kernel(DtwArgs g) 
     pb.bnd = g.bnd + (size_t)pair * sdp::n_strips(g.M) * g.N;
     pb.entb = g.entb + (size_t)pair * sdp::n_strips(g.M) * g.N;
     pb.err = g.err;
-    for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x)
+    sdp::for_each_rowgroup(g.ticket + pair, g.n_rg, [&](int rg) {
         sdp::run_rowgroup<sdp::DtwPolicy, true, H>(pb, rg, g.n_rg, g.n_strips_wg, dtw_smem);
+    });
 }
 
 __global__ void __launch_bounds__(64) dtw_hops_kernel(DtwArgs g) {
@@ -141,6 +143,30 @@ __global__ void __launch_bounds__(256) dtw_back_decode_kernel(DtwArgs g) {
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Workgroups of dtw_sdp_kernel<3> (one strip each) / <2> (two strips each) the current device holds at once;
+// queried once per device and LDS padding (sdp::pick_config, "Residency").
+static void dtw_residency(int &r1, int &r2) {
+    static int cache[16][3];  // [device]: pad + 1, r1, r2
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t pad = sdp::lds_pad();
+    int *c = (dev >= 0 && dev < 16) ? cache[dev] : nullptr;
+    if (c && c[0] == (int)pad + 1) {
+        r1 = c[1];
+        r2 = c[2];
+        return;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    r1 = sdp::resident_blocks(dtw_sdp_kernel<3>, 256, sdp::lds_bytes(1) + pad);
+    r2 = sdp::resident_blocks(dtw_sdp_kernel<2>, 384, sdp::lds_bytes(2) + pad);
+    if (c) {
+        c[1] = r1;
+        c[2] = r2;
+        c[0] = (int)pad + 1;
+    }
+}
+
 }  // namespace rts
 
 extern "C" {
@@ -153,7 +179,7 @@ int rts_dtw_workspace_bytes(int M, int N, int B, size_t *bytes) {
     *bytes = 256 + align256(sizeof(unsigned long long) * strips * N) + align256(sizeof(int32_t) * strips * N) +
              2 * align256(sizeof(int32_t) * strips) + align256(sizeof(double) * (size_t)B * N * sdp::kYRec) +
              align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N)) +
-             align256(sizeof(int32_t) * 2 * (size_t)B * sdp::scratch_pairs(M, N));
+             align256(sizeof(int32_t) * 2 * (size_t)B * sdp::scratch_pairs(M, N)) + align256(sizeof(int32_t) * (size_t)B);
     return RTS_OK;
 }
 
@@ -177,8 +203,11 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
     if (((uintptr_t)ws_dev & 15) != 0) return set_error(RTS_ERR_INVALID, "workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int strips = sdp::n_strips(M);
-    int NS, H, G;
-    sdp::pick_config(strips, B, NS, H, G);
+    int NS, H, G, res1 = 0, res2 = 0;
+    dtw_residency(res1, res2);
+    if (res1 < 1 && res2 < 1)
+        return set_error(RTS_ERR_HIP, "the occupancy query reports no resident workgroup for the strip-DP kernel on this device");
+    sdp::pick_config(strips, B, res1, res2, NS, H, G);
     const int n_rg = (strips + NS - 1) / NS;
     unsigned char *ws = reinterpret_cast<unsigned char *>(ws_dev);
     DtwArgs g;
@@ -211,10 +240,13 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
         g.codes = reinterpret_cast<uint32_t *>(p);
         p += align256(sizeof(uint32_t) * (size_t)B * sdp::codes_words(M, N));
         g.pscr = reinterpret_cast<int32_t *>(p);
+        p += align256(sizeof(int32_t) * 2 * (size_t)B * sdp::scratch_pairs(M, N));
+        g.ticket = reinterpret_cast<int32_t *>(p);
     }
     g.n_rg = n_rg;
     g.n_strips_wg = NS;
     RTS_HIP(hipMemsetAsync(g.err, 0, 16, s));
+    RTS_HIP(hipMemsetAsync(g.ticket, 0, sizeof(int32_t) * (size_t)B, s));
     if (n_rg > 1) RTS_HIP(hipMemsetD32Async((hipDeviceptr_t)g.bnd, (int)sdp::kSentinel32, (size_t)2 * B * strips * N, s));
     {
         const dim3 grid((N + 255) / 256, (M + kCostRows - 1) / kCostRows, B);
@@ -229,16 +261,11 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
     }
     RTS_HIP(hipGetLastError());
     hipLaunchKernelGGL(dtw_prep_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, g);
-    const size_t smem = sdp::lds_bytes(NS);
-    if (H == 2) {
-        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t smem = sdp::lds_bytes(NS) + sdp::lds_pad();
+    if (H == 2)
         hipLaunchKernelGGL((dtw_sdp_kernel<2>), dim3(G, B), dim3(64 * NS * 3), smem, s, g);
-    } else {
-        RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<3>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else
         hipLaunchKernelGGL((dtw_sdp_kernel<3>), dim3(G, B), dim3(64 * NS * 4), smem, s, g);
-    }
     RTS_HIP(hipGetLastError());
     if (strips <= sdp::kTailStrips) {
         hipLaunchKernelGGL(dtw_tail_kernel, dim3(B), dim3(64 * strips), sdp::tail_lds_bytes(strips), s, g);

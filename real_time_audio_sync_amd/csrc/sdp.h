@@ -67,19 +67,46 @@ __host__ __device__ inline size_t lds_bytes(int NS) {
 // Strips per workgroup / helper waves per strip / workgroups of one problem's pipeline.  One strip per workgroup
 // (3 helpers; the DP wave, which sets the pace, has a SIMD to itself; 77 KB of LDS, so two workgroups share a CU) when
 // every strip of every problem can have a resident workgroup of its own; otherwise two strips per workgroup (2 helpers
-// each), which halves the number of passes a workgroup makes over the columns.  A problem's row groups wait for one
-// another inside the launch, so all of them must be resident: `grid` workgroups per problem at most.
-// RTS_SDP_CONFIG=1|2 forces the strips per workgroup (tuning; results do not depend on it).
-inline void pick_config(int strips, int B, int &NS, int &H, int &grid) {
-    NS = ((long long)strips * B <= 512) ? 1 : 2;
+// each), which halves the number of passes a workgroup makes over the columns.
+//
+// Residency.  A problem's row groups wait for one another inside the launch (run_rowgroup polls the bottom row of the
+// row group above).  That is deadlock-free WHATEVER the residency, because row groups are not bound to workgroups:
+// a workgroup takes the next row group of its problem from a ticket counter when it starts and whenever it finishes
+// one (for_each_rowgroup), so row group r - 1 was always taken by a workgroup that is already running -- by induction it
+// finishes, and r with it.  `resident1` / `resident2` (workgroups of the one-strip / two-strip kernel the device holds
+// at once: compute units x hipOccupancyMaxActiveBlocksPerMultiprocessor, queried by the caller for the instantiation
+// it launches) only size the grid: workgroups beyond residency would just queue behind the running ones.
+// RTS_SDP_CONFIG=1|2 forces the strips per workgroup, RTS_SDP_GRID=n the workgroups per problem (tuning and tests;
+// results do not depend on either).
+inline void pick_config(int strips, int B, int resident1, int resident2, int &NS, int &H, int &grid) {
+    if (resident1 < 1) resident1 = 1;
+    if (resident2 < 1) resident2 = 1;
+    NS = ((long long)strips * B <= resident1) ? 1 : 2;
     if (const char *e = getenv("RTS_SDP_CONFIG")) NS = (atoi(e) == 1) ? 1 : 2;
     if (NS > strips) NS = strips;
     H = (NS == 1) ? 3 : 2;
     const int n_rg = (strips + NS - 1) / NS;
-    const int resident = (NS == 1) ? 512 : 256;  // 256 CUs x workgroups per CU
+    const int resident = (NS == 1) ? resident1 : resident2;
     grid = resident / B;
     if (grid < 1) grid = 1;
     if (grid > n_rg) grid = n_rg;
+    if (const char *e = getenv("RTS_SDP_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+}
+// Test knob: extra bytes of dynamic LDS per workgroup (lowers the residency the occupancy query reports and the
+// hardware grants, e.g. 80000 -> one workgroup per CU); 0 in production.
+inline size_t lds_pad() {
+    const char *e = getenv("RTS_SDP_LDS_PAD");
+    const long v = e ? atol(e) : 0;
+    return v > 0 && v < 80 * 1024 ? (size_t)v : 0;
+}
+// Workgroups of `kernel` (block threads, smem bytes of dynamic LDS) resident on the current device at once.
+template <typename K>
+inline int resident_blocks(K kernel, int block, size_t smem) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, smem) != hipSuccess) return 0;
+    return cus * per_cu;
 }
 __host__ __device__ inline size_t codes_words(int M, int N) { return (size_t)n_strips(M) * n_chunks(N) * 64; }
 
@@ -319,6 +346,21 @@ __host__ __device__ constexpr bool helper_takes_rows(int H, int hidx, int it) { 
     return hidx == 1;
 }
 
+// Row groups are handed out by ticket (see pick_config, "Residency"): `ticket` is a zero-initialised device word per
+// problem; f(rg) runs the row group with the whole workgroup.
+template <typename F>
+__device__ __forceinline__ void for_each_rowgroup(int32_t *ticket, int n_rg, F f) {
+    __shared__ int s_rowgroup;
+    for (;;) {
+        __syncthreads();  // every wave is done with the previous row group (LDS tiles, s_rowgroup)
+        if (threadIdx.x == 0) s_rowgroup = atomicAdd(ticket, 1);
+        __syncthreads();
+        const int rg = __builtin_amdgcn_readfirstlane(s_rowgroup);
+        if (rg >= n_rg) break;
+        f(rg);
+    }
+}
+
 // ---- one row group (NS strips) of one problem, executed by the whole workgroup ----------------------------------
 // Waves: block 0 = helper 0 of strips 0..NS-1, block 1 = the DP waves, blocks 2.. = further helpers (with NS = 2 and
 // H = 2 the two DP waves are waves 2 and 3 and have a SIMD to themselves).
@@ -361,7 +403,9 @@ __device__ __forceinline__ void run_rowgroup(const Problem &pb, int rg, int n_rg
         }
         const double nx = P::norm(x);
         int ent = 0, ent_upprev = 0;  // helper 0: entry columns (see Problem::entb) of my row's last cell / its upper-left
-        bool dead = false;            // helper 0: a poll of the row-group boundary ran into its bound
+        // helper 0: a poll of the row-group boundary ran into its bound (here or, recorded in *err, anywhere
+        // in the launch: the fault is reported once, the remaining row groups run through without polling)
+        bool dead = (__hip_atomic_load(pb.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
 #ifdef RTS_SDP_STAMPS
         long long sh_cost = 0, sh_flush = 0, sh_bar = 0;
 #endif

@@ -56,6 +56,7 @@ struct WtwArgs {
     int32_t *cross, *lens;     // [B][n_strips(W)] strip-boundary crossings / segment lengths of the window's path
     double *yrec;              // [B][W][14] prepared records of the window's reference columns
     int32_t *err;
+    int32_t *ticket;           // [B] next row group of the pending window (sdp::for_each_rowgroup); zeroed by the control step
     int n_rg, n_strips_wg;
     int M, N, W, hopf, path_cap;
     int fill_separate;         // long windows: the hand-over's fill and column records by wtw_big_fill_kernel
@@ -281,8 +282,9 @@ __global__ void __launch_bounds__(H == 2 ? 384 : 256) wtw_big_dp_kernel(WtwArgs 
     pb.bnd = g.bnd + (size_t)b * sdp::n_strips(g.W) * g.W;
     pb.entb = g.entb + (size_t)b * sdp::n_strips(g.W) * g.W;
     pb.err = g.err;
-    for (int rg = blockIdx.x; rg < g.n_rg; rg += gridDim.x)
+    sdp::for_each_rowgroup(g.ticket + b, g.n_rg, [&](int rg) {
         sdp::run_rowgroup<sdp::WtwPolicy, STAGE, H>(pb, rg, g.n_rg, g.n_strips_wg, wtw_smem);
+    });
 }
 
 // find_path (wtw.py:219-240) for the pending window of each stream, over the packed step codes (sdp.h): the
@@ -411,6 +413,7 @@ __device__ __forceinline__ void wtw_ctl_body(const WtwArgs &g) {
         st[5] = n_windows;
         st[6] = (int32_t)(uint32_t)(cells & 0xffffffffLL);
         st[7] = (int32_t)(uint32_t)((unsigned long long)cells >> 32);
+        g.ticket[b] = 0;  // the DP launch that follows hands its row groups out from 0 again
         ctl[0] = next_pending;
         ctl[1] = live_ptr;
         ctl[2] = ref_ptr;
@@ -477,7 +480,7 @@ struct rts_wtw {
     int32_t *appended, *state, *path;
     int8_t *bwork;
     double *dlast;
-    int32_t *ws_sub, *ws_scr, *ctl, *err, *entb, *cross, *lens;
+    int32_t *ws_sub, *ws_scr, *ctl, *err, *ticket, *entb, *cross, *lens;
     double *yrec;
     uint32_t *codes;
     unsigned long long *bnd;
@@ -485,6 +488,18 @@ struct rts_wtw {
     int device;  // the HIP device the handle's buffers live on
     size_t smem;
 };
+
+namespace rts {
+// A handle belongs to the device that was current at rts_wtw_create (like rts_otw handles).
+static int wtw_check_device(const rts_wtw *h) {
+    int d = -1;
+    RTS_HIP(hipGetDevice(&d));
+    if (d != h->device)
+        return set_error(RTS_ERR_INVALID, "handle was created on device %d but device %d is current "
+                                          "(one process per GPU, or hipSetDevice before the call)", h->device, d);
+    return RTS_OK;
+}
+}  // namespace rts
 
 extern "C" {
 
@@ -524,12 +539,26 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     h->use_big = big;
     if (big) {
         int nw, nh, grid;
-        sdp::pick_config(sdp::n_strips(W), B, nw, nh, grid);
+        // workgroups of the one-strip / two-strip DP kernel this device holds at once (sdp::pick_config, "Residency")
+        const size_t pad = sdp::lds_pad();
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_big_dp_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const int res1 = keep_last_d ? sdp::resident_blocks(wtw_big_dp_kernel<true, 3>, 256, sdp::lds_bytes(1) + pad)
+                                     : sdp::resident_blocks(wtw_big_dp_kernel<false, 3>, 256, sdp::lds_bytes(1) + pad);
+        const int res2 = keep_last_d ? sdp::resident_blocks(wtw_big_dp_kernel<true, 2>, 384, sdp::lds_bytes(2) + pad)
+                                     : sdp::resident_blocks(wtw_big_dp_kernel<false, 2>, 384, sdp::lds_bytes(2) + pad);
+        if (res1 < 1 && res2 < 1) {
+            free(h);
+            return set_error(RTS_ERR_HIP, "the occupancy query reports no resident workgroup for the strip-DP kernel on this device");
+        }
+        sdp::pick_config(sdp::n_strips(W), B, res1, res2, nw, nh, grid);
         h->big_waves = nw;
         h->big_helpers = nh;
         h->n_rg = (sdp::n_strips(W) + nw - 1) / nw;
         h->big_grid = grid;
-        h->smem = sdp::lds_bytes(nw);
+        h->smem = sdp::lds_bytes(nw) + pad;
     } else {
         h->smem = sizeof(double) * ((size_t)2 * W * kWF + 2 * W + 3 * W) + sizeof(int32_t) * 4 * W +
                   (W <= kWtwLdsB ? (size_t)W * W : 0) + 64;
@@ -544,6 +573,7 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         (big && (e = hipMalloc((void **)&h->ws_scr, sizeof(int32_t) * 2 * sdp::scratch_pairs(W, W) * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->ctl, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->err, 16)) != hipSuccess) ||
+        (big && (e = hipMalloc((void **)&h->ticket, sizeof(int32_t) * (size_t)B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->codes, sizeof(uint32_t) * sdp::codes_words(W, W) * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->bnd, sizeof(unsigned long long) * (size_t)sdp::n_strips(W) * W * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->entb, sizeof(int32_t) * (size_t)sdp::n_strips(W) * W * B)) != hipSuccess) ||
@@ -591,6 +621,7 @@ int rts_wtw_destroy(rts_wtw *h) {
     if (h->ws_scr) (void)hipFree(h->ws_scr);
     if (h->ctl) (void)hipFree(h->ctl);
     if (h->err) (void)hipFree(h->err);
+    if (h->ticket) (void)hipFree(h->ticket);
     if (h->codes) (void)hipFree(h->codes);
     if (h->bnd) (void)hipFree(h->bnd);
     if (h->entb) (void)hipFree(h->entb);
@@ -604,6 +635,9 @@ int rts_wtw_destroy(rts_wtw *h) {
 int rts_wtw_reset(rts_wtw *h, void *stream) {
     using namespace rts;
     if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (h->state) {  // (rts_wtw_create resets before the handle is complete; the device is current there by construction)
+        if (int rc = wtw_check_device(h); rc != RTS_OK) return rc;
+    }
     hipStream_t s = (hipStream_t)stream;
     RTS_HIP(hipMemsetAsync(h->appended, 0, sizeof(int32_t) * (size_t)h->B, s));
     RTS_HIP(hipMemsetAsync(h->state, 0, sizeof(int32_t) * 8 * (size_t)h->B, s));
@@ -611,6 +645,7 @@ int rts_wtw_reset(rts_wtw *h, void *stream) {
     RTS_HIP(hipMemsetAsync(h->live, 0, sizeof(double) * kWF * (size_t)h->N * h->B, s));
     if (h->ctl) RTS_HIP(hipMemsetAsync(h->ctl, 0, sizeof(int32_t) * 8 * (size_t)h->B, s));
     if (h->err) RTS_HIP(hipMemsetAsync(h->err, 0, 16, s));
+    if (h->ticket) RTS_HIP(hipMemsetAsync(h->ticket, 0, sizeof(int32_t) * (size_t)h->B, s));
     return RTS_OK;
 }
 
@@ -621,13 +656,7 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     if (n_max < 0) return set_error(RTS_ERR_INVALID, "n_max < 0");
     if (n_max > 0 && !cols_dev) return set_error(RTS_ERR_INVALID, "cols_dev is NULL");
     if (cols_dtype != RTS_F32 && cols_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad cols_dtype %d", cols_dtype);
-    {
-        int d = -1;
-        RTS_HIP(hipGetDevice(&d));
-        if (d != h->device)
-            return set_error(RTS_ERR_INVALID, "handle was created on device %d but device %d is current "
-                                              "(one process per GPU, or hipSetDevice before the call)", h->device, d);
-    }
+    if (int rc = wtw_check_device(h); rc != RTS_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (precheck) {
         hipLaunchKernelGGL(wtw_precheck_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, h->state, h->B, h->M, h->N);
@@ -655,6 +684,7 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
     g.lens = h->lens;
     g.yrec = h->yrec;
     g.err = h->err;
+    g.ticket = h->ticket;
     g.n_rg = h->n_rg;
     g.fill_separate = ((size_t)(h->n_rg > 1 ? h->n_rg - 1 : 0) * h->W > (1u << 16)) ? 1 : 0;  // more than 0.5 MB of boundary words
     g.n_strips_wg = h->big_waves;
@@ -705,6 +735,7 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
 int rts_wtw_read_states(rts_wtw *h, int32_t *states, void *stream) {
     using namespace rts;
     if (!h || !states) return set_error(RTS_ERR_INVALID, "NULL argument");
+    if (int rc = wtw_check_device(h); rc != RTS_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     RTS_HIP(hipMemcpyAsync(states, h->state, sizeof(int32_t) * 8 * (size_t)h->B, hipMemcpyDeviceToHost, s));
     RTS_HIP(hipStreamSynchronize(s));
@@ -715,6 +746,7 @@ int rts_wtw_read_path(rts_wtw *h, int b, int32_t *pairs, int cap_pairs, int *n, 
     using namespace rts;
     if (!h || !n) return set_error(RTS_ERR_INVALID, "NULL argument");
     if (b < 0 || b >= h->B) return set_error(RTS_ERR_INVALID, "stream index %d out of range [0, %d)", b, h->B);
+    if (int rc = wtw_check_device(h); rc != RTS_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     int32_t np = 0;
     RTS_HIP(hipMemcpyAsync(&np, h->state + (size_t)b * 8 + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -735,6 +767,7 @@ int rts_wtw_read_last_d(rts_wtw *h, int b, double *d_host, void *stream) {
     if (!h || !d_host) return set_error(RTS_ERR_INVALID, "NULL argument");
     if (b < 0 || b >= h->B) return set_error(RTS_ERR_INVALID, "stream index %d out of range [0, %d)", b, h->B);
     if (!h->dlast) return set_error(RTS_ERR_INVALID, "handle was created with keep_last_d = 0");
+    if (int rc = wtw_check_device(h); rc != RTS_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     RTS_HIP(hipMemcpyAsync(d_host, h->dlast + (size_t)b * h->W * h->W, sizeof(double) * (size_t)h->W * h->W,
                            hipMemcpyDeviceToHost, s));

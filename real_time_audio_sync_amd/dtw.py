@@ -9,11 +9,15 @@ from . import _native as nat
 from .otw_batch import frames_tensor, _np_dtype_code
 
 
-def dtw_batch(a_dev, b_dev, want_back=True):
+def dtw_batch(a_dev, b_dev, want_back=True, check=False):
     """a_dev: [B][M][12] or [M][12] (shared), b_dev: [B][N][12] or [N][12] (shared); device
     tensors, float32/float64.  Returns device tensors (cost [B][M][N] f64, acc [B][M][N] f64,
     back [B][M][N] int8 -- None unless want_back --, path [B][M+N][2] int32, path_len [B] int32).
-    Asynchronous."""
+    Asynchronous.
+
+    Fault contract: ``path_len[k] == -1`` means the device pipeline reported a fault (a bounded in-launch wait between
+    workgroups ran out -- never expected); the other outputs of that call are then not to be used.  ``check=True``
+    synchronises and raises RtsyncError instead of leaving that to the caller."""
     dev = a_dev.device
     sa = a_dev.dim() == 2
     sb = b_dev.dim() == 2
@@ -34,6 +38,8 @@ def dtw_batch(a_dev, b_dev, want_back=True):
                               back.data_ptr() if back is not None else None, path.data_ptr(),
                               plen.data_ptr(), ws.data_ptr(), nbytes.value,
                               ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    if check and int(plen.min().item()) < 1:
+        raise nat.RtsyncError("rts_dtw: the device pipeline reported a fault (path_len = -1)")
     return cost, acc, back, path, plen
 
 

@@ -65,11 +65,7 @@ class BatchedOTW:
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            if torch.cuda.current_device() == self.device.index:
-                nat.lib.rts_otw_destroy(h)
-            else:
-                with torch.cuda.device(self.device):
-                    nat.lib.rts_otw_destroy(h)
+            nat.destroy_on(self.device, nat.lib.rts_otw_destroy, h)
 
     __del__ = close
 

@@ -32,7 +32,7 @@ class BatchedWTW(object):
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            nat.lib.rts_wtw_destroy(h)
+            nat.destroy_on(self.device, nat.lib.rts_wtw_destroy, h)
 
     __del__ = close
 

@@ -89,9 +89,8 @@ def test_dtw_config1_sizes():
 
 
 def test_dtw_long_sequences_hbm_diagonals():
-    """Beyond 6400 rows the three anti-diagonals move from LDS to an HBM workspace (rts_dtw_ws).  7000 x 900
-    against the oracle, then a 30-minute-sized pair (19 380 x 19 380: 3 GB each for cost and acc_cost) through
-    size-independent properties."""
+    """Long pairs: the strip pipeline spans hundreds of workgroups (csrc/sdp.h).  7000 x 900 against the oracle, then a
+    30-minute-sized pair (19 380 x 19 380: 3 GB each for cost and acc_cost) through size-independent properties."""
     import oracle
     from real_time_audio_sync_amd import _native as nat, synth
     from real_time_audio_sync_amd.dtw import DTW, dtw_batch
@@ -101,14 +100,12 @@ def test_dtw_long_sequences_hbm_diagonals():
     cost, acc, path = DTW(a, b)
     ocost, oacc, opath, _ = oracle.dtw(a, b)
     assert np.array_equal(path, opath) and np.array_equal(acc, oacc) and np.array_equal(cost, ocost)
-    # the plain entry point refuses, with a message that names the way out
     dev = torch.device("cuda:0")
     n = 19380
     ref = synth.synth_ref(n, seed=80)
     live = synth.synth_live(ref, seed=81)
     ad, bd = frames_tensor(live, dev, torch.float32), frames_tensor(ref, dev, torch.float32)
-    cost, acc, back, pth, plen = dtw_batch(ad, bd)
-    torch.cuda.synchronize()
+    cost, acc, back, pth, plen = dtw_batch(ad, bd, check=True)
     m = ad.shape[0]
     p = pth[0, : int(plen[0])].cpu().numpy()
     assert tuple(p[0]) == (0, 0) and tuple(p[-1]) == (m - 1, n - 1)
@@ -138,8 +135,7 @@ def test_dtw_batched_pipelines_side_by_side():
     for tdt in (torch.float64, torch.float32):
         a = torch.stack([frames_tensor(l, dev, tdt) for l in lives])       # [6][700][12]: 11 strips per pair
         b = frames_tensor(ref, dev, tdt)
-        cost, acc, back, path, plen = dtw_batch(a, b)
-        torch.cuda.synchronize()
+        cost, acc, back, path, plen = dtw_batch(a, b, check=True)
         for k, l in enumerate(lives):
             lk = l.astype(np.float32).astype(np.float64) if tdt == torch.float32 else l
             rk = ref.astype(np.float32).astype(np.float64) if tdt == torch.float32 else ref

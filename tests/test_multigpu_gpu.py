@@ -1,6 +1,12 @@
-"""bench.py's N>1 branch over RCCL (backend "nccl"), one process per GPU, on however many gfx950 devices the box
-has -- the path the driver's scaling run takes.  Skipped on a one-GPU box (RCCL refuses two ranks on one
-device; the 2-rank rehearsal over gloo lives in tests/test_shard_cpu.py)."""
+"""bench.py's N>1 branch (BASELINE configs[3]: streams sharded 64 per GPU, no data-path collective).
+
+  * test_bench_two_ranks_on_one_device: ALWAYS runs -- a fresh child `python -m torch.distributed.run --nproc-per-node 2
+    bench.py --gpus 2`, both ranks on device 0 (BENCH_SINGLE_DEVICE=1) with the report reductions over gloo
+    (BENCH_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).  Everything else is the driver's N>1 path: contiguous
+    partition, per-rank engines, barrier / max-clock, and the parity gate over EVERY stream of EVERY rank.
+  * test_bench_single_process_shards: ALWAYS runs -- `bench.py --gpus 2 --single-process` (shard.ShardedOTW), same line.
+  * test_bench_over_rccl_on_all_devices: the same over RCCL on however many gfx950 devices the box has (skipped on a
+    one-GPU box)."""
 import json
 import os
 import socket
@@ -22,6 +28,52 @@ def _free_port():
     return p
 
 
+def _bench_line(cmd, env, timeout=900):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _check_sharded_line(r, n, per_gpu):
+    assert r["n_gpus"] == n and r["scaling"] == "weak"
+    assert r["config"]["streams_total"] == per_gpu * n and r["config"]["streams_per_gpu"] == per_gpu
+    assert r["config"]["workload"].startswith("configs[3]") and "contiguous" in r["config"]["partition"]
+    # every stream of every rank was checked against the C port, none differs
+    assert r["parity"]["streams_checked"] == r["parity"]["streams_total"] == per_gpu * n
+    assert r["parity"]["path_mismatches"] == 0 and r["value"] > 0
+    assert "cpu_baseline" not in r and "secondary" not in r          # N = 1 figures by contract
+    assert abs(r["value"] - r["config"]["frames_per_step"] / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+
+
+def test_bench_two_ranks_on_one_device():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_SINGLE_DEVICE="1", BENCH_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16", "--n-ref", "600", "--c", "100"]
+    r = _bench_line(cmd, env)
+    _check_sharded_line(r, 2, 16)
+    assert "gloo" in r["config"]["launcher"]
+    # the frames of the two shards add up to what one process counts for the same 32 streams
+    one = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                       "--batch", "32", "--n-ref", "600", "--c", "100", "--no-numpy"], dict(os.environ))
+    assert one["config"]["frames_per_step"] == r["config"]["frames_per_step"]
+    assert one["parity"]["streams_checked"] == 32 and one["parity"]["path_mismatches"] == 0
+
+
+def test_bench_single_process_shards():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, BENCH_SINGLE_DEVICE="1")
+    r = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--steps", "3",
+                     "--warmup", "1", "--batch", "16", "--n-ref", "600", "--c", "100"], env)
+    _check_sharded_line(r, 2, 16)
+    assert "ShardedOTW" in r["config"]["launcher"]
+
+
 def test_bench_over_rccl_on_all_devices():
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
@@ -35,12 +87,8 @@ def test_bench_over_rccl_on_all_devices():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(n), "--steps", "3", "--warmup", "1", "--batch", "8", "--n-ref", "500", "--c", "100"]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-3000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    r = json.loads(line)
-    assert r["n_gpus"] == n and r["scaling"] == "weak" and r["config"]["streams_total"] == 8 * n
-    assert r["parity"]["path_mismatches"] == 0 and r["value"] > 0
+    r = _bench_line(cmd, env, timeout=600)
+    _check_sharded_line(r, n, 8)
 
 
 def test_one_process_many_devices():

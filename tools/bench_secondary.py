@@ -55,6 +55,7 @@ def main():
         l = synth.synth_live(r, seed=n + 1, max_frames=n)
         a, b = frames_tensor(l, dev, torch.float32), frames_tensor(r, dev, torch.float32)
         t = timed(lambda: dtw.dtw_batch(a, b, want_back=False))
+        assert int(dtw.dtw_batch(a, b, want_back=False, check=True)[4].min()) > 0
         cells = a.shape[0] * b.shape[0]
         out.append(dict(kernel="rts_dtw (cost + strip DP + backtrack)", M=int(a.shape[0]), N=int(b.shape[0]), pairs=1,
                         seconds=t, cells_per_s=cells / t, algorithmic_bytes=cells * 16.25,
