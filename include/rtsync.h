@@ -37,6 +37,7 @@ extern "C" {
 /* dtype of feature / sample buffers handed to the library */
 #define RTS_F32 0
 #define RTS_F64 1
+#define RTS_I16 2 /* PCM16 samples, rts_live_* only: value / 32768 in float32, exactly what librosa.load returns for a WAV */
 
 /* which reference class an OTW handle follows */
 #define RTS_VARIANT_OTW 0         /* otw_eran.py:5   OnlineTimeWarping (sentinel 1e10, run_count starts 1) */
@@ -214,6 +215,9 @@ int rts_chroma_frames_batch(rts_chroma *h, const void *samples_dev, int sample_d
                             const int32_t *n_frames_dev, int normalize, void *chroma_out_dev, int out_dtype,
                             void *stream);
 
+/* fft_len and hop of a plan (either pointer may be NULL). */
+int rts_chroma_plan_info(const rts_chroma *h, int *fft_len, int *hop);
+
 /* create_chroma(ft) for a power spectrum that is already on the device: spec_dev [n_frames][fft_len/2+1]. */
 int rts_chroma_project(rts_chroma *h, const double *spec_dev, int n_frames, int normalize, void *chroma_out_dev,
                        int out_dtype, void *stream);
@@ -266,6 +270,49 @@ int rts_wtw_read_path(rts_wtw *h, int b, int32_t *pairs, int cap_pairs, int *n, 
 int rts_wtw_read_last_d(rts_wtw *h, int b, double *d_host, void *stream);
 /* Device views: live chroma history [B][2M][F] float64 and (if kept) the last window's D [B][W][W]. */
 int rts_wtw_device_views(rts_wtw *h, double **live_chroma_dev, int *live_capacity, double **last_d_dev);
+
+/* Device view of the state vectors, [B][RTS_WTW_STATE_LEN] int32 (zero-copy consumers; rts_live_* publishes from it). */
+int rts_wtw_state_view(rts_wtw *h, int32_t **state_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Live ingestion: raw audio buffers of B microphones -> chroma columns -> alignment state, all on the device.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rts_live rts_live;
+
+/* Replaces the audio loops that feed the trackers, for B streams per call:
+ *   livenote_live.py:161-209  receive_audio / _process_input: once >= fft_len samples are pending,
+ *                             `while len(data) >= 4096: col = wav_to_chroma_col(data[:4096]); ln.insert(col); data = data[2048:]`
+ *   wtw.py:71-93              WTW.insert(list): self.buf += list; `while len(self.buf) >= fft_len:` one column per hop
+ * Binds a chroma plan (its fft_len / hop; un-padded framing, chroma.py:35-42) and exactly one of `otw` (created with
+ * the same B; columns go through rts_otw_push) or `wtw` (rts_wtw_push with precheck, i.e. wtw.py:76-77 once per feed).
+ * The plan and the tracker must outlive the handle and live on the current device.  max_pending: capacity in samples of
+ * each stream's pending buffer (>= fft_len + hop); a feed that would exceed it is refused with RTS_ERR_INVALID.
+ * All calls of one handle must use the same `stream`. */
+int rts_live_create(rts_chroma *plan, rts_otw *otw, rts_wtw *wtw, int B, int max_pending, rts_live **out);
+int rts_live_destroy(rts_live *h);
+/* Drops pending samples and resets the bound tracker.  Synchronises `stream`. */
+int rts_live_reset(rts_live *h, void *stream);
+
+/* One feed, zero-copy form.  rts_live_staging hands out the next pinned host staging slot (it waits only if the feed
+ * that used the slot four feeds ago has not been consumed by the device yet): the producer writes counts_host[b] = new
+ * samples of stream b and the samples of all streams packed back to back in stream order (float32 or int16) to
+ * samples_host (capacity_samples = B * max_pending).  rts_live_submit then enqueues, without synchronising anything:
+ * one host-to-device copy of the used part of the slot (on an internal copy stream, so that it overlaps the kernels of
+ * the previous feed), append to the per-stream pending buffers, chroma of every complete hop, push into the tracker,
+ * drop of the consumed samples (hop per column, livenote_live.py:208 / wtw.py:83), publication of the status words. */
+int rts_live_staging(rts_live *h, int32_t **counts_host, void **samples_host, long long *capacity_samples);
+int rts_live_submit(rts_live *h, int sample_kind /* RTS_F32 | RTS_I16 */, void *stream);
+/* The same from caller-owned host arrays (one memcpy into the staging slot): samples_host packed like above. */
+int rts_live_feed(rts_live *h, const void *samples_host, int sample_kind, const int32_t *counts_host, void *stream);
+
+/* Non-blocking look at what the device last published (host-mapped memory, written at the end of every feed):
+ * status[b] (RTS_RUNNING / RTS_STOP_REF_END = insert() returned "stop" / ...), positions[2b] = live frame index
+ * (t / live_ptr), positions[2b+1] = reference frame index (j / ref_ptr); *feeds_done = feeds whose results these words
+ * reflect for every stream, *feeds_submitted = feeds enqueued so far.  Any pointer may be NULL. */
+int rts_live_poll(rts_live *h, int32_t *status /* [B] */, int32_t *positions /* [B][2] */, int *feeds_done,
+                  int *feeds_submitted);
+/* Samples pending per stream after everything submitted so far (the host-side mirror; exact). */
+int rts_live_pending(rts_live *h, long long *pending_host /* [B] */);
 
 #ifdef __cplusplus
 }

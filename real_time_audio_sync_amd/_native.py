@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("RTSYNC_LIB") or os.path.join(_HERE, "librtsync.so")
 
 # constants mirrored from include/rtsync.h
-F32, F64 = 0, 1
+F32, F64, I16 = 0, 1, 2
 VARIANT_OTW, VARIANT_LIVENOTE, VARIANT_LIVENOTE_V2 = 0, 1, 2
 COST_DOT, COST_EUCLID = 0, 1
 DIR_NONE, DIR_BOTH, DIR_ROW, DIR_COLUMN = -1, 0, 1, 2
@@ -77,6 +77,7 @@ _decl("rts_chroma_create", _i32, [_i32, _i32, _vp, _vp, ctypes.POINTER(_vp)])
 _decl("rts_chroma_destroy", _i32, [_vp])
 _decl("rts_chroma_frames", _i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp])
 _decl("rts_chroma_frames_batch", _i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp])
+_decl("rts_chroma_plan_info", _i32, [_vp, _pi32, _pi32])
 _decl("rts_chroma_project", _i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp])
 _decl("rts_chroma_diff", _i32, [_vp, _i32, _i32, _vp, _vp])
 
@@ -89,7 +90,17 @@ _decl("rts_wtw_read_states", _i32, [_vp, _vp, _vp])
 _decl("rts_wtw_read_path", _i32, [_vp, _i32, _vp, _i32, _pi32, _vp])
 _decl("rts_wtw_read_last_d", _i32, [_vp, _i32, _vp, _vp])
 _decl("rts_wtw_device_views", _i32, [_vp, ctypes.POINTER(_vp), _pi32, ctypes.POINTER(_vp)])
+_decl("rts_wtw_state_view", _i32, [_vp, ctypes.POINTER(_vp)])
 WTW_STATE_LEN = 8
+
+_decl("rts_live_create", _i32, [_vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_vp)])
+_decl("rts_live_destroy", _i32, [_vp])
+_decl("rts_live_reset", _i32, [_vp, _vp])
+_decl("rts_live_staging", _i32, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64)])
+_decl("rts_live_submit", _i32, [_vp, _i32, _vp])
+_decl("rts_live_feed", _i32, [_vp, _vp, _i32, _vp, _vp])
+_decl("rts_live_poll", _i32, [_vp, _vp, _vp, _pi32, _pi32])
+_decl("rts_live_pending", _i32, [_vp, _vp])
 
 
 def check(rc):

@@ -753,6 +753,13 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
     return RTS_OK;
 }
 
+int rts_chroma_plan_info(const rts_chroma *h, int *fft_len, int *hop) {
+    if (!h) return rts::set_error(RTS_ERR_INVALID, "handle is NULL");
+    if (fft_len) *fft_len = h->L;
+    if (hop) *hop = h->hop;
+    return RTS_OK;
+}
+
 int rts_chroma_destroy(rts_chroma *h) {
     if (!h) return RTS_OK;
     if (h->window) (void)hipFree(h->window);

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(H == 2 ? 384 : 256) dtw_sdp_kernel(DtwArgs g) 
     pb.bnd = g.bnd + (size_t)pair * sdp::n_strips(g.M) * g.N;
     pb.entb = g.entb + (size_t)pair * sdp::n_strips(g.M) * g.N;
     pb.err = g.err;
-    sdp::for_each_rowgroup(g.ticket + pair, g.n_rg, [&](int rg) {
+    sdp::for_each_rowgroup(g.ticket + pair, g.n_rg, g.n_strips_wg, dtw_smem, [&](int rg) {
         sdp::run_rowgroup<sdp::DtwPolicy, true, H>(pb, rg, g.n_rg, g.n_strips_wg, dtw_smem);
     });
 }
@@ -145,7 +145,7 @@ static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Workgroups of dtw_sdp_kernel<3> (one strip each) / <2> (two strips each) the current device holds at once;
 // queried once per device and LDS padding (sdp::pick_config, "Residency").
-static void dtw_residency(int &r1, int &r2) {
+static int dtw_residency(int &r1, int &r2) {
     static int cache[16][3];  // [device]: pad + 1, r1, r2
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -154,10 +154,10 @@ static void dtw_residency(int &r1, int &r2) {
     if (c && c[0] == (int)pad + 1) {
         r1 = c[1];
         r2 = c[2];
-        return;
+        return RTS_OK;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dtw_sdp_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     r1 = sdp::resident_blocks(dtw_sdp_kernel<3>, 256, sdp::lds_bytes(1) + pad);
     r2 = sdp::resident_blocks(dtw_sdp_kernel<2>, 384, sdp::lds_bytes(2) + pad);
     if (c) {
@@ -165,6 +165,7 @@ static void dtw_residency(int &r1, int &r2) {
         c[2] = r2;
         c[0] = (int)pad + 1;
     }
+    return RTS_OK;
 }
 
 }  // namespace rts
@@ -204,7 +205,7 @@ int rts_dtw(const void *a_dev, int a_dtype, long long a_stride, const void *b_de
     hipStream_t s = (hipStream_t)stream;
     const int strips = sdp::n_strips(M);
     int NS, H, G, res1 = 0, res2 = 0;
-    dtw_residency(res1, res2);
+    if (int rc = dtw_residency(res1, res2); rc != RTS_OK) return rc;
     if (res1 < 1 && res2 < 1)
         return set_error(RTS_ERR_HIP, "the occupancy query reports no resident workgroup for the strip-DP kernel on this device");
     sdp::pick_config(strips, B, res1, res2, NS, H, G);

@@ -61,9 +61,12 @@ constexpr int kDiag = 2;  // from (i-1, j-1)
 
 __host__ __device__ inline int n_strips(int M) { return (M + 63) / 64; }
 __host__ __device__ inline int n_chunks(int N) { return (N + 63 + kChunk - 1) / kChunk; }  // per strip
-__host__ __device__ inline size_t lds_bytes(int NS) {
+__host__ __device__ inline size_t lds_core_bytes(int NS) {
     return sizeof(double) * (size_t)NS * ((size_t)kRing * 64 + (size_t)kTiles * kChunk * kStageLd + 2 * kChunk * kYRec + 64 + 2 * kChunk);
 }
+// + 16 bytes behind the strips' buffers: the workgroup's current ticket (for_each_rowgroup).  All of it is dynamic LDS --
+// the kernels declare no static LDS, so that the dynamic limit can be raised to the full 160 KB.
+__host__ __device__ inline size_t lds_bytes(int NS) { return lds_core_bytes(NS) + 16; }
 // Strips per workgroup / helper waves per strip / workgroups of one problem's pipeline.  One strip per workgroup
 // (3 helpers; the DP wave, which sets the pace, has a SIMD to itself; 77 KB of LDS, so two workgroups share a CU) when
 // every strip of every problem can have a resident workgroup of its own; otherwise two strips per workgroup (2 helpers
@@ -103,9 +106,11 @@ inline size_t lds_pad() {
 template <typename K>
 inline int resident_blocks(K kernel, int block, size_t smem) {
     int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, smem) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, smem) != hipSuccess) {
+        (void)hipGetLastError();  // a configuration that does not fit (e.g. padded LDS) is an answer, not a sticky error
+        return 0;
+    }
     return cus * per_cu;
 }
 __host__ __device__ inline size_t codes_words(int M, int N) { return (size_t)n_strips(M) * n_chunks(N) * 64; }
@@ -349,13 +354,13 @@ __host__ __device__ constexpr bool helper_takes_rows(int H, int hidx, int it) { 
 // Row groups are handed out by ticket (see pick_config, "Residency"): `ticket` is a zero-initialised device word per
 // problem; f(rg) runs the row group with the whole workgroup.
 template <typename F>
-__device__ __forceinline__ void for_each_rowgroup(int32_t *ticket, int n_rg, F f) {
-    __shared__ int s_rowgroup;
+__device__ __forceinline__ void for_each_rowgroup(int32_t *ticket, int n_rg, int NS, unsigned char *smem, F f) {
+    volatile int *slot = reinterpret_cast<volatile int *>(smem + lds_core_bytes(NS));
     for (;;) {
-        __syncthreads();  // every wave is done with the previous row group (LDS tiles, s_rowgroup)
-        if (threadIdx.x == 0) s_rowgroup = atomicAdd(ticket, 1);
+        __syncthreads();  // every wave is done with the previous row group (LDS tiles, the slot)
+        if (threadIdx.x == 0) *slot = atomicAdd(ticket, 1);
         __syncthreads();
-        const int rg = __builtin_amdgcn_readfirstlane(s_rowgroup);
+        const int rg = __builtin_amdgcn_readfirstlane(*slot);
         if (rg >= n_rg) break;
         f(rg);
     }

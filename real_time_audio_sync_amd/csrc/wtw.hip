@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(H == 2 ? 384 : 256) wtw_big_dp_kernel(WtwArgs 
     pb.bnd = g.bnd + (size_t)b * sdp::n_strips(g.W) * g.W;
     pb.entb = g.entb + (size_t)b * sdp::n_strips(g.W) * g.W;
     pb.err = g.err;
-    sdp::for_each_rowgroup(g.ticket + b, g.n_rg, [&](int rg) {
+    sdp::for_each_rowgroup(g.ticket + b, g.n_rg, g.n_strips_wg, wtw_smem, [&](int rg) {
         sdp::run_rowgroup<sdp::WtwPolicy, STAGE, H>(pb, rg, g.n_rg, g.n_strips_wg, wtw_smem);
     });
 }
@@ -772,6 +772,13 @@ int rts_wtw_read_last_d(rts_wtw *h, int b, double *d_host, void *stream) {
     RTS_HIP(hipMemcpyAsync(d_host, h->dlast + (size_t)b * h->W * h->W, sizeof(double) * (size_t)h->W * h->W,
                            hipMemcpyDeviceToHost, s));
     RTS_HIP(hipStreamSynchronize(s));
+    return RTS_OK;
+}
+
+int rts_wtw_state_view(rts_wtw *h, int32_t **state_dev) {
+    using namespace rts;
+    if (!h || !state_dev) return set_error(RTS_ERR_INVALID, "NULL argument");
+    *state_dev = h->state;
     return RTS_OK;
 }
 
