@@ -112,8 +112,8 @@ def check(rc):
 def destroy_on(device, destroy_fn, handle):
     """Free a handle's device buffers with the handle's own device current (hipFree of a foreign device's pointer
     from another current device is an error the destroy functions cannot report)."""
-    import torch
     try:
+        import torch
         if device.index is None or torch.cuda.current_device() == device.index:
             destroy_fn(handle)
         else:

@@ -37,9 +37,8 @@ def test_int16_and_float_feeds_agree_with_the_oracle(chopin_audio, otw_golden):
     what could move an OTW decision on real audio; the same comparison test_live_gpu.py makes)."""
     from real_time_audio_sync_amd.live import LiveSession
     ref_chroma = otw_golden["G/ref"]
-    live = chopin_audio["live"]
-    pcm = np.round(live * 32768.0).astype(np.int16)            # what the WAV held: live == pcm / 32768 exactly
-    assert np.array_equal(pcm.astype(np.float32) / np.float32(32768.0), live)
+    pcm = np.round(chopin_audio["live"] * 32768.0).astype(np.int16)     # the recording as a mono PCM16 microphone would deliver it
+    live = pcm.astype(np.float32) / np.float32(32768.0)                # ... and as librosa.load would return that (exact)
     lens = (len(live), len(live) // 3, len(live) - 12345, 5000)
     want = _offline_paths(ref_chroma, [live[:n] for n in lens], 50)
     for dt in (np.float32, np.int16):
@@ -106,9 +105,11 @@ def test_feed_block_stop_and_overflow_reporting():
     ref = synth.synth_ref(30, seed=3)
     sess = LiveSession(ref, batch=5, c=10, max_run_count=3, max_pending=3 * 4096)
     rs = np.random.RandomState(1)
+    sess.feed_block((rs.rand(5, 4096) - 0.5).astype(np.float32))             # leaves 2048 samples pending per stream
     with pytest.raises(nat.RtsyncError):
-        sess.feed_block((rs.rand(5, 3 * 4096 + 1) - 0.5).astype(np.float32))   # more than max_pending at once
-    for _ in range(40):                                                       # 40 x 4096 samples = 80 hops > 2N = 60 frames
+        sess.feed_block((rs.rand(5, 3 * 4096) - 0.5).astype(np.float32))     # 2048 + 12288 > max_pending: refused, nothing changes
+    assert (sess.pending() == 2048).all()
+    for _ in range(39):                                                       # 40 x 4096 samples = 80 hops > 2N = 60 frames
         sess.feed_block((rs.rand(5, 4096) - 0.5).astype(np.float32))
     sess.sync()
     info = sess.poll()
