@@ -9,7 +9,7 @@
 //          (rts_live_staging hands the slot out, so a producer can write there directly) and copied by one
 //          hipMemcpyAsync on the handle's copy stream; the compute stream waits for that copy by event, so the copy of
 //          feed k+1 overlaps the kernels of feed k (a ring of kSlots pinned + device slots).
-//   live_append_kernel    per stream: append the new samples (float32, or PCM16 scaled by 1/32768 like librosa.load)
+//   live_append_kernel    per stream (16 slices each): append the new samples (float32, or PCM16 scaled by 1/32768 like librosa.load)
 //                         behind the pending ones in a per-stream device buffer; pending -> n_samples, complete hops ->
 //                         n_frames  ((pending - fft_len) / hop + 1 once pending >= fft_len).
 //   rts_chroma_frames_batch   un-padded framing of every stream's pending samples -> chroma columns [B][n_max][12]
@@ -43,7 +43,6 @@ struct LiveArgs {
     int state_len, st_status, st_live, st_ref;
     int32_t *pub;                // host-mapped [B][kLiveWords]
     int feed_no;
-    int publish;                 // append kernel: publish here (no column will be produced by this feed)
 };
 
 __device__ __forceinline__ void live_publish(const LiveArgs &g, int b) {
@@ -56,6 +55,10 @@ __device__ __forceinline__ void live_publish(const LiveArgs &g, int b) {
     p[3] = g.feed_no;  // written last: a reader that sees feed k sees the three words of feed >= k
 }
 
+constexpr int kAppendSlices = 16;  // workgroups per stream in the append kernel (a 1-second buffer is 88 KB)
+
+// grid (B, kAppendSlices): slice y of stream b copies its share of the new samples behind the pending ones.  `pending`
+// is only read here (every slice needs the same base); the compact kernel, which always follows, writes it.
 __global__ void __launch_bounds__(256) live_append_kernel(LiveArgs g) {
     const int b = blockIdx.x;
     const int32_t *counts = reinterpret_cast<const int32_t *>(g.stage);
@@ -66,25 +69,27 @@ __global__ void __launch_bounds__(256) live_append_kernel(LiveArgs g) {
     if (p + n > g.cap) n = g.cap - p;  // (the host refuses such a feed before it gets here)
     const long long off = offs[b];
     float *dst = g.buf + (size_t)b * g.cap + p;
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * per, hi = (lo + per < n) ? lo + per : n;
     if (g.sample_kind == RTS_F32) {
         const float *src = reinterpret_cast<const float *>(g.stage + g.samples_off) + off;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) dst[i] = src[i];
     } else {
         const int16_t *src = reinterpret_cast<const int16_t *>(g.stage + g.samples_off) + off;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = (float)src[i] * (1.0f / 32768.0f);  // exact
+        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) dst[i] = (float)src[i] * (1.0f / 32768.0f);  // exact
     }
-    if (threadIdx.x == 0) {
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
         const int q = p + n;
-        g.pending[b] = q;
         g.n_samples[b] = q;
         g.n_frames[b] = q >= g.L ? (q - g.L) / g.hop + 1 : 0;
-        if (g.publish) live_publish(g, b);
     }
 }
 
-__global__ void __launch_bounds__(256) live_compact_kernel(LiveArgs g) {
+// One workgroup per stream, after the tracker has taken the columns (or right after the append when no stream completed
+// a hop): drops the consumed samples and publishes.
+__global__ void __launch_bounds__(1024) live_compact_kernel(LiveArgs g) {
     const int b = blockIdx.x;
-    const int p = g.pending[b];
+    const int p = g.n_samples[b];
     const int used = g.n_frames[b] * g.hop;
     const int rem = p - used;
     float *buf = g.buf + (size_t)b * g.cap;
@@ -323,16 +328,15 @@ int rts_live_submit(rts_live *h, int sample_kind, void *stream) {
     g.st_ref = h->st_ref;
     g.pub = h->pub_dev;
     g.feed_no = h->feeds;
-    g.publish = (n_max == 0 && !h->wtw);
-    hipLaunchKernelGGL(live_append_kernel, dim3(B), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(live_append_kernel, dim3(B, kAppendSlices), dim3(256), 0, s, g);
     RTS_HIP(hipGetLastError());
     RTS_HIP(hipEventRecord(h->done[k], s));  // the staging slot (host and device side) is free again after this point
     if (n_max == 0) {
-        if (h->wtw) {  // wtw.py:76-77 runs on every insert(), new column or not; then publish what it decided
+        if (h->wtw) {  // wtw.py:76-77 runs on every insert(), new column or not
             if (int rc = rts_wtw_push(h->wtw, nullptr, RTS_F64, 0, nullptr, 1, stream); rc != RTS_OK) return rc;
-            hipLaunchKernelGGL(live_compact_kernel, dim3(B), dim3(256), 0, s, g);  // nothing to drop: n_frames = 0
-            RTS_HIP(hipGetLastError());
         }
+        hipLaunchKernelGGL(live_compact_kernel, dim3(B), dim3(1024), 0, s, g);  // nothing to drop: pending, publication
+        RTS_HIP(hipGetLastError());
         return RTS_OK;
     }
     int rc = rts_chroma_frames_batch(h->plan, h->buf, RTS_F32, h->cap, h->n_samples, 0, B, n_max, h->n_frames, 1, h->cols,
@@ -341,7 +345,7 @@ int rts_live_submit(rts_live *h, int sample_kind, void *stream) {
     rc = h->otw ? rts_otw_push(h->otw, h->cols, RTS_F64, n_max, h->n_frames, stream)
                 : rts_wtw_push(h->wtw, h->cols, RTS_F64, n_max, h->n_frames, 1, stream);
     if (rc != RTS_OK) return rc;
-    hipLaunchKernelGGL(live_compact_kernel, dim3(B), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(live_compact_kernel, dim3(B), dim3(1024), 0, s, g);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

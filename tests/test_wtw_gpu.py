@@ -143,6 +143,36 @@ def test_config5_window_10000():
     eng.close()
 
 
+def test_config5_window_against_the_reference_fixture():
+    """configs[4] pinned by the REFERENCE: tests/golden/wtw10k_golden.json holds what wtw.py's own get_cost_matrix /
+    run_dtw / find_path gave for the first W = 10 000 window of this workload (tests/golden/make_wtw10k_golden.py, 15
+    minutes of the reference's Python; the C port was checked equal there): sha256 of D's last row and last column,
+    D[-1, -1], and of the path WTW.insert hands over with dtw_hop = 5 000 frames (wtw.py:107-117)."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    from real_time_audio_sync_amd import synth
+    from real_time_audio_sync_amd.wtw import BatchedWTW
+    gold = json.load(open(os.path.join(GOLDEN, "wtw10k_golden.json")))
+    assert "reference" in gold and gold["reference"] == gold["oracle"]
+    dev = torch.device("cuda:0")
+    ref = synth.synth_ref(19380, seed=500)
+    live = synth.synth_live(ref, seed=501)[:, :10000]
+    eng = BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev), 10000, 5000, 1, keep_last_d=True)
+    eng.push(torch.from_numpy(np.ascontiguousarray(live.T))[None].to(dev), precheck=True)
+    st = eng.state()
+    assert st["windows"] == 1 and st["cells"] == 10000 * 10000 and st["status"] == 0
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    p = eng.path().astype(np.int32)
+    assert len(p) == gold["path_len"] and sha(p) == gold["path_sha256"]
+    D = eng.last_d()
+    assert float(D[-1, -1]) == gold["reference"]["d_end"]
+    assert sha(D[-1]) == gold["reference"]["d_last_row_sha"]
+    assert sha(np.ascontiguousarray(D[:, -1])) == gold["reference"]["d_last_col_sha"]
+    eng.close()
+
+
 def test_randomized_small_windows():
     """Seeded sweep: window sizes from 1 frame up, hops from 1 to W, references barely longer than a
     window, live streams shorter / longer than the reference, silent (all-zero) frames -> NaN costs."""
