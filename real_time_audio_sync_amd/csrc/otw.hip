@@ -2099,6 +2099,7 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     if (!out) return set_error(RTS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!ref_dev) return set_error(RTS_ERR_INVALID, "ref_dev is NULL");
+    if (F < 1) return set_error(RTS_ERR_INVALID, "F must be >= 1 (got %d)", F);
     if (F != kF) return set_error(RTS_ERR_UNSUPPORTED, "F must be 12 chroma bins (got %d)", F);
     if (N < 1 || B < 1) return set_error(RTS_ERR_INVALID, "N and B must be >= 1 (got N=%d B=%d)", N, B);
     if (ref_dtype != RTS_F32 && ref_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad ref_dtype %d", ref_dtype);

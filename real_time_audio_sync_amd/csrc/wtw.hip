@@ -509,6 +509,7 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     if (!out) return set_error(RTS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!chroma_ref_dev) return set_error(RTS_ERR_INVALID, "chroma_ref_dev is NULL");
+    if (F < 1) return set_error(RTS_ERR_INVALID, "F must be >= 1 (got %d)", F);
     if (F != kWF) return set_error(RTS_ERR_UNSUPPORTED, "F must be 12 chroma bins (got %d)", F);
     if (M < 1 || B < 1) return set_error(RTS_ERR_INVALID, "M and B must be >= 1");
     if (win_frames < 1) return set_error(RTS_ERR_INVALID, "dtw_win_size / hop_size must be >= 1 frame");
