@@ -260,6 +260,238 @@ __global__ void __launch_bounds__(256) wtw_advance_kernel(WtwArgs g) {
     }
 }
 
+// ---- windows of at most kWinMaxW frames: every window of a push in ONE launch, one workgroup per stream -------------
+//
+// wtw_live.py runs W = 100 / hop = 50, tests.py:174 W = 20 / hop = 10: thousands of small windows per stream, each one
+// depending on the hand-over of the one before.  wtw_win_kernel<R> keeps a stream's whole window loop on the device:
+//   1. all 256 threads: the window's live / reference frames into LDS, norms, then the full n x m cost matrix
+//      (1 - x.y / (|x| |y|), wtw.py:169, the reference's dot orders) into LDS;
+//   2. R waves run the DP with one matrix row per lane and the lanes skewed in time (lane l handles column t - l at
+//      step t), so the three predecessors of a cell are registers: the lane's own previous value, the previous value of
+//      lane l - 1 (DPP wave_shr:1) and what that move delivered one step earlier.  Same float64 operations and the same
+//      candidate order as wtw.py:201-215 (up, left, diag; strict '<'), so D and the path are bit-identical.  With
+//      R = 2 (64 < W <= 128) wave 1 owns rows 64.. and runs 5 blocks of 16 steps behind wave 0, whose bottom row it
+//      reads from LDS; one workgroup barrier per 16 steps.  Step codes: 2 bits per cell, 16 steps of a lane per dword.
+//   3. wave 0 walks the path back (find_path, wtw.py:219-240): the position lives in SGPRs, every lane holds the code
+//      word of its row for the current 16 steps, the code is one v_readlane away;
+//   4. all threads: hand-over (wtw.py:107-128) and the column bookkeeping up to the next window in closed form
+//      (the same rules as wtw_ctl_body below).
+constexpr int kWinMaxW = 128;
+constexpr int kWinKW = 12;  // code words per lane: 64 + 128 - 1 steps at most
+
+__host__ __device__ inline int win_ldc(int W) { return (W | 1) + 1; }  // even > W: lanes a row apart hit different LDS banks
+__host__ __device__ inline size_t win_lds_bytes(int W) {
+    const size_t feat = sizeof(double) * (2 * (size_t)W * kWF + 2 * (size_t)W);            // xs, ys, nx, ny
+    const size_t walk = sizeof(uint32_t) * 2 * kWinKW * 64 + sizeof(double) * (size_t)W +  // codes, bottom row of wave 0
+                        sizeof(int32_t) * 4 * (size_t)W;                                   // sub-path
+    return sizeof(double) * (size_t)W * win_ldc(W) + (feat > walk ? feat : walk) + 128;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) wtw_win_kernel(WtwArgs g) {
+    extern __shared__ __align__(16) unsigned char wtw_smem[];
+    const int W = g.W, ldc = win_ldc(W);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int32_t *sh = reinterpret_cast<int32_t *>(wtw_smem);                 // [32] control words
+    double *C = reinterpret_cast<double *>(wtw_smem + 128);              // [W][ldc]
+    unsigned char *scratch = reinterpret_cast<unsigned char *>(C + (size_t)W * ldc);
+    // phase 1/2 view of the scratch area
+    double *xs = reinterpret_cast<double *>(scratch);
+    double *ys = xs + (size_t)W * kWF;
+    double *nx = ys + (size_t)W * kWF;
+    double *ny = nx + W;
+    // phase 3/4 view (the features are dead once the costs exist)
+    uint32_t *codes = reinterpret_cast<uint32_t *>(scratch);            // [2][kWinKW][64]
+    double *bot = reinterpret_cast<double *>(codes + 2 * kWinKW * 64);   // [W] bottom row of wave 0
+    int32_t *sub = reinterpret_cast<int32_t *>(bot + W);                 // [2W][2], reversed
+
+    int32_t *st = g.state + (size_t)b * 8;
+    const double *live = g.live + (size_t)b * g.N * kWF;
+    int32_t *path = g.path + (size_t)b * g.path_cap * 2;
+    const int appended_raw = g.appended[b];
+    const int appended = appended_raw < g.N ? appended_raw : g.N;
+    // state in registers (uniform: every thread computes the same values)
+    int chroma_ptr = st[0], live_ptr = st[1], ref_ptr = st[2], status = st[3], n_path = st[4], n_windows = st[5];
+    long long cells = ((long long)(uint32_t)st[7] << 32) | (uint32_t)st[6];
+
+    for (;;) {
+        // ---- wtw.py:92-100 in closed form up to the next window (see wtw_ctl_body)
+        int pending = 0, m = 0;
+        const int n = W;
+        if (status == RTS_RUNNING && chroma_ptr < appended) {
+            if (ref_ptr >= (g.M - 1 - W) || live_ptr >= (g.N - 1 - W)) {
+                chroma_ptr += 1;
+                status = RTS_STOP_REF_END;
+            } else if (live_ptr + W <= appended) {
+                chroma_ptr = live_ptr + W;
+                m = W;
+                if (ref_ptr + m > g.M) m = g.M - ref_ptr;
+                pending = m > 0 ? 1 : 0;
+                if (!pending) chroma_ptr = appended;
+            } else {
+                chroma_ptr = appended;
+            }
+        }
+        if (!pending) break;
+        const int lp = live_ptr, rp = ref_ptr;
+        // ---- 1. features, norms, cost matrix
+        __syncthreads();  // the previous window's walk / hand-over is done with the scratch area
+        for (int idx = tid; idx < n * kWF; idx += 256) xs[idx] = live[(size_t)lp * kWF + idx];
+        for (int idx = tid; idx < m * kWF; idx += 256) ys[idx] = g.ref[(size_t)rp * kWF + idx];
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) nx[i] = sqrt(wtw_dot_chain(xs + i * kWF, xs + i * kWF));
+        for (int j = tid; j < m; j += 256) ny[j] = sqrt(wtw_dot_chain(ys + j * kWF, ys + j * kWF));
+        __syncthreads();
+        for (int idx = tid; idx < n * m; idx += 256) {
+            const int i = idx / m, j = idx - i * m;
+            const double dot = wtw_dot_strided(xs + i * kWF, ys + j * kWF);
+            C[(size_t)i * ldc + j] = 1.0 - dot / (nx[i] * ny[j]);  // wtw.py:169
+        }
+        __syncthreads();
+        // ---- 2. DP: wave r owns rows 64 r .. 64 r + 63
+        {
+            const int r = wave;
+            const int rows = (r < R) ? ((n - 64 * r) < 64 ? (n - 64 * r) : 64) : 0;  // <= 0: nothing to do
+            const int T = rows > 0 ? rows + m - 1 : 0;
+            const int blocks = (T + 15) >> 4;
+            const int rounds_all = (R == 1) ? ((n + m - 1 + 15) >> 4)
+                                            : (((64 + m - 1 + 15) >> 4) > (5 + ((n - 64 + m - 1 + 15) >> 4)) ? ((64 + m - 1 + 15) >> 4)
+                                                                                                               : (5 + ((n - 64 + m - 1 + 15) >> 4)));
+            const int i = 64 * r + lane;
+            const bool row_ok = lane < rows;
+            double dlast_v = 0.0, du_prev = 0.0;
+            double *dout = g.dlast ? g.dlast + ((size_t)b * W + i) * W : nullptr;
+            for (int k = 0; k < rounds_all; k++) {
+                if (R > 1) lds_barrier();  // wave 1 reads bottom-row values wave 0 wrote at least one round ago
+                const int kb = k - 5 * r;
+                if (kb < 0 || kb >= blocks) continue;  // wave-uniform
+                uint32_t word = 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int t = 16 * kb + q;
+                    const int j = t - lane;
+                    const bool valid = row_ok && j >= 0 && j < m;
+                    const double c = C[valid ? (size_t)i * ldc + j : 0];
+                    double lane0_in = 0.0;
+                    if (R > 1 && r > 0) lane0_in = bot[(t < m) ? t : 0];  // lane 0 of wave 1: (i - 1, j) = wave 0's bottom row
+                    const double du = sdp::shr1(dlast_v, lane0_in);      // D[i-1][j]
+                    const double dl = dlast_v;                            // D[i][j-1]
+                    const double dd = du_prev;                            // D[i-1][j-1]
+                    double dv;
+                    uint32_t code;
+                    if (i == 0 && j == 0) {
+                        dv = c;
+                        code = 0;
+                    } else if (j == 0) {
+                        dv = du + c;  // wtw.py:187-191
+                        code = 3;
+                    } else if (i == 0) {
+                        dv = dl + c;  // wtw.py:194-198
+                        code = 1;
+                    } else {
+                        double mc = du;  // wtw.py:201-215: up, then left, then diag, strict '<'
+                        code = 3;
+                        if (dl < mc) {
+                            mc = dl;
+                            code = 1;
+                        }
+                        if (dd < mc) {
+                            mc = dd;
+                            code = 2;
+                        }
+                        dv = mc + c;
+                    }
+                    du_prev = du;
+                    if (valid) {
+                        dlast_v = dv;
+                        word |= code << (2 * q);
+                        if (R > 1 && r == 0 && lane == 63) bot[j] = dv;
+                        if (dout) dout[j] = dv;
+                    }
+                }
+                codes[((size_t)r * kWinKW + kb) * 64 + lane] = word;
+            }
+        }
+        __syncthreads();
+        // ---- 3. find_path (wtw.py:219-240) by wave 0: sub[] holds the path reversed, sh[0] its length
+        if (wave == 0) {
+            int i = n - 1, j = m - 1, len = 1;
+            if (lane == 0) {
+                sub[0] = i;
+                sub[1] = j;
+            }
+            int cur = -1;
+            uint32_t cw = 0;
+            while (!(i == 0 && j == 0) && len < 2 * W) {
+                const int r = i >> 6, l = i & 63;
+                const int t = l + j;
+                const int key = r * kWinKW + (t >> 4);
+                if (key != cur) {  // uniform
+                    cw = codes[(size_t)key * 64 + lane];
+                    cur = key;
+                }
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cw, l);
+                const int code = (int)((w >> (2 * (t & 15))) & 3u);
+                if (code == 1)
+                    j -= 1;
+                else if (code == 2) {
+                    i -= 1;
+                    j -= 1;
+                } else
+                    i -= 1;
+                i = __builtin_amdgcn_readfirstlane(i);
+                j = __builtin_amdgcn_readfirstlane(j);
+                if (lane == 0) {
+                    sub[2 * len] = i;
+                    sub[2 * len + 1] = j;
+                }
+                len++;
+            }
+            if (lane == 0) {
+                sh[0] = len;
+                sh[1] = 0;
+            }
+        }
+        __syncthreads();
+        // ---- 4. hand-over (wtw.py:107-128): l is non-decreasing along the path, so the points with l <= dtw_hop / hop
+        // are a prefix of it
+        const int len = sh[0];
+        int local = 0;
+        for (int f = tid; f < len; f += 256) local += (sub[2 * (len - 1 - f)] <= g.hopf) ? 1 : 0;
+        if (local) atomicAdd(&sh[1], local);
+        __syncthreads();
+        const int cnt = sh[1];
+        for (int f = tid; f < cnt; f += 256) {
+            if (n_path + f < g.path_cap) {
+                path[2 * (size_t)(n_path + f)] = sub[2 * (len - 1 - f)] + lp;
+                path[2 * (size_t)(n_path + f) + 1] = sub[2 * (len - 1 - f) + 1] + rp;
+            }
+        }
+        if (cnt < len && cnt >= 1) {  // "change": the path went past the hop (wtw.py:118-124)
+            live_ptr = lp + sub[2 * (len - cnt)];
+            ref_ptr = rp + sub[2 * (len - cnt) + 1];
+        } else {
+            live_ptr = lp + g.hopf;
+            ref_ptr = rp + g.hopf;
+        }
+        n_path += cnt;
+        n_windows += 1;
+        cells += (long long)n * m;
+    }
+    if (status == RTS_RUNNING && chroma_ptr >= g.N && appended_raw > g.N) status = RTS_LIVE_OVERFLOW;
+    if (tid == 0) {
+        st[0] = chroma_ptr;
+        st[1] = live_ptr;
+        st[2] = ref_ptr;
+        st[3] = status;
+        st[4] = n_path;
+        st[5] = n_windows;
+        st[6] = (int32_t)(uint32_t)(cells & 0xffffffffLL);
+        st[7] = (int32_t)(uint32_t)((unsigned long long)cells >> 32);
+    }
+}
+
 // ---- windows of more than kWtwLdsW frames: strip DP over many workgroups (sdp.h) ------------------------------
 
 // H helper waves per strip: <.., 2> two strips per workgroup, <.., 3> one strip per workgroup (sdp::pick_config).
@@ -485,6 +717,7 @@ struct rts_wtw {
     uint32_t *codes;
     unsigned long long *bnd;
     int big_waves, big_helpers, n_rg, big_grid, use_big;
+    int use_win;  // windows of at most kWinMaxW frames: wtw_win_kernel (0: off, 1 / 2: DP waves)
     int device;  // the HIP device the handle's buffers live on
     size_t smem;
 };
@@ -536,7 +769,13 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     // RTS_WTW_BIG_FROM overrides the threshold (tuning and tests; results do not depend on it).
     int big_from = kWtwStripFrom;
     if (const char *e = getenv("RTS_WTW_BIG_FROM")) big_from = atoi(e) < kWtwLdsW ? atoi(e) : kWtwLdsW;
-    const bool big = W > big_from;
+    // Windows of at most 128 frames: the one-launch window kernel (RTS_WTW_WIN=0 or an explicit RTS_WTW_BIG_FROM select the
+    // older paths: tests and A/B runs; results are identical).
+    bool win = W <= kWinMaxW;
+    if (const char *e = getenv("RTS_WTW_WIN")) win = win && atoi(e) != 0;
+    if (getenv("RTS_WTW_BIG_FROM")) win = false;
+    h->use_win = win ? (W <= 64 ? 1 : 2) : 0;
+    const bool big = !win && W > big_from;
     h->use_big = big;
     if (big) {
         int nw, nh, grid;
@@ -560,6 +799,8 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         h->n_rg = (sdp::n_strips(W) + nw - 1) / nw;
         h->big_grid = grid;
         h->smem = sdp::lds_bytes(nw) + pad;
+    } else if (win) {
+        h->smem = win_lds_bytes(W);
     } else {
         h->smem = sizeof(double) * ((size_t)2 * W * kWF + 2 * W + 3 * W) + sizeof(int32_t) * 4 * W +
                   (W <= kWtwLdsB ? (size_t)W * W : 0) + 64;
@@ -569,7 +810,11 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         (e = hipMalloc((void **)&h->appended, sizeof(int32_t) * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->state, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->path, sizeof(int32_t) * 2 * (size_t)h->path_cap * B)) != hipSuccess ||
-        (!big && W > kWtwLdsB && (e = hipMalloc((void **)&h->bwork, (size_t)B * W * W)) != hipSuccess) ||
+        (!big && !win && W > kWtwLdsB && (e = hipMalloc((void **)&h->bwork, (size_t)B * W * W)) != hipSuccess) ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_win_kernel<1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_win_kernel<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
         (big && (e = hipMalloc((void **)&h->ws_sub, sizeof(int32_t) * 4 * (size_t)W * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->ws_scr, sizeof(int32_t) * 2 * sdp::scratch_pairs(W, W) * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->ctl, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess) ||
@@ -724,6 +969,10 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
             }
             if (g.fill_separate) hipLaunchKernelGGL(wtw_big_fill_kernel, dim3(128, h->B), dim3(256), 0, s, g);
         }
+    } else if (h->use_win == 1) {
+        hipLaunchKernelGGL((wtw_win_kernel<1>), dim3(h->B), dim3(256), h->smem, s, g);
+    } else if (h->use_win == 2) {
+        hipLaunchKernelGGL((wtw_win_kernel<2>), dim3(h->B), dim3(256), h->smem, s, g);
     } else if (h->W > kWtwLdsB) {
         hipLaunchKernelGGL((wtw_advance_kernel<false>), dim3(h->B), dim3(kWtwNT), h->smem, s, g);
     } else {

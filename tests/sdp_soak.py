@@ -69,7 +69,10 @@ def run(n_trials=60, seed=5, verbose=True):
                     lv[:, int(rs.randint(0, lv.shape[1]))] = 0.0   # a silent frame: NaN costs (wtw.py:169)
                 lives.append(lv)
             keep = bool(rs.rand() < 0.4)
+            # windows of at most 128 frames: odd trials on the strip-DP path (RTS_WTW_WIN=0), even ones on wtw_win_kernel
+            os.environ["RTS_WTW_WIN"] = "0" if trial % 2 else "1"
             eng = BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev), W, hopf, B, keep_last_d=keep)
+            os.environ.pop("RTS_WTW_WIN", None)
             tmax = max(l.shape[1] for l in lives)
             cols = np.zeros((B, tmax, 12))
             for k, l in enumerate(lives):

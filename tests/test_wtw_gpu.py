@@ -32,7 +32,7 @@ def test_wtw_known_answer_on_gpu(chopin_audio, wtw_known_answer):
     assert wtw.insert([0.0] * 10) == "stop"  # sticky
 
 
-def test_windows_against_reference_vectors(wtw_window_golden):
+def test_windows_against_reference_vectors(wtw_window_golden, wtw_path):
     """One window = get_cost_matrix + run_dtw + find_path of the reference (called directly in
     make_golden.py).  The window is forced by giving the handle a reference a few frames longer
     than the window and hop = W-1 so the whole sub-path is handed over."""
@@ -54,7 +54,16 @@ def test_windows_against_reference_vectors(wtw_window_golden):
         eng.close()
 
 
-def test_batched_streams_vs_oracle():
+@pytest.fixture(params=["win", "older"])
+def wtw_path(request, monkeypatch):
+    """Windows of at most 128 frames run on wtw_win_kernel (every window of a push in one launch); RTS_WTW_WIN=0 selects
+    the older kernels (anti-diagonal sweep up to 64 frames, strip DP above), which stay covered this way."""
+    if request.param == "older":
+        monkeypatch.setenv("RTS_WTW_WIN", "0")
+    return request.param
+
+
+def test_batched_streams_vs_oracle(wtw_path):
     """Synthetic chroma, several streams, W=20/hop=10 and W=100/hop=50 (wtw_live.py's setting)."""
     import oracle
     from real_time_audio_sync_amd import synth
@@ -173,7 +182,7 @@ def test_config5_window_against_the_reference_fixture():
     eng.close()
 
 
-def test_randomized_small_windows():
+def test_randomized_small_windows(wtw_path):
     """Seeded sweep: window sizes from 1 frame up, hops from 1 to W, references barely longer than a
     window, live streams shorter / longer than the reference, silent (all-zero) frames -> NaN costs."""
     import oracle
@@ -182,7 +191,7 @@ def test_randomized_small_windows():
     dev = torch.device("cuda:0")
     rs = np.random.RandomState(77)
     for trial in range(40):
-        W = int(rs.choice([1, 2, 3, 5, 8, 16, 20, 33, 64, 127, 128, 129, 200]))
+        W = int(rs.choice([1, 2, 3, 5, 8, 16, 20, 33, 63, 64, 65, 100, 127, 128, 129, 200]))
         hopf = int(rs.randint(1, W + 1))
         M = int(W + rs.choice([1, 2, 3, 10, 60, 150]))
         ref = synth.synth_ref(M, seed=trial)
