@@ -263,48 +263,66 @@ __global__ void __launch_bounds__(256) wtw_advance_kernel(WtwArgs g) {
 // ---- windows of at most kWinMaxW frames: every window of a push in ONE launch, one workgroup per stream -------------
 //
 // wtw_live.py runs W = 100 / hop = 50, tests.py:174 W = 20 / hop = 10: thousands of small windows per stream, each one
-// depending on the hand-over of the one before.  wtw_win_kernel<R> keeps a stream's whole window loop on the device:
-//   1. all 256 threads: the window's live / reference frames into LDS, norms, then the full n x m cost matrix
-//      (1 - x.y / (|x| |y|), wtw.py:169, the reference's dot orders) into LDS;
-//   2. R waves run the DP with one matrix row per lane and the lanes skewed in time (lane l handles column t - l at
-//      step t), so the three predecessors of a cell are registers: the lane's own previous value, the previous value of
-//      lane l - 1 (DPP wave_shr:1) and what that move delivered one step earlier.  Same float64 operations and the same
-//      candidate order as wtw.py:201-215 (up, left, diag; strict '<'), so D and the path are bit-identical.  With
-//      R = 2 (64 < W <= 128) wave 1 owns rows 64.. and runs 5 blocks of 16 steps behind wave 0, whose bottom row it
-//      reads from LDS; one workgroup barrier per 16 steps.  Step codes: 2 bits per cell, 16 steps of a lane per dword.
+// depending on the hand-over of the one before.  wtw_win_kernel<R, STAGE> keeps a stream's whole window loop on the device:
+//   1. all 256 threads: the full n x m cost matrix (1 - x.y / (|x| |y|), wtw.py:169, the reference's dot orders) into LDS
+//      -- lanes own columns (reference frame and norm in registers), waves share the rows (live frames broadcast from LDS);
+//   2. row 0 and column 0 of D are plain running sums (wtw.py:187-198): two lanes accumulate them, in the reference's
+//      order, into LDS.  The interior runs on R waves with one matrix row per lane and the lanes skewed in time (lane l of
+//      wave r owns row 1 + 64 r + l and handles column 1 + t - l at step t), so the three predecessors of a cell are
+//      registers: the lane's own previous value, the previous value of the lane above (DPP wave_shr:1; lane 0 receives
+//      row 0, or wave 0's bottom row, from LDS) and what that move delivered one step earlier.  Same float64 operations and
+//      candidate order as wtw.py:201-215 (sdp::WtwPolicy::cell), so D and the path are bit-identical.  With R = 2
+//      (65 < W <= 128) wave 1 runs 5 blocks of 16 steps behind wave 0; one workgroup barrier per 16 steps.
+//      Step codes: 2 bits per cell, 16 steps of a lane per dword.
 //   3. wave 0 walks the path back (find_path, wtw.py:219-240): the position lives in SGPRs, every lane holds the code
 //      word of its row for the current 16 steps, the code is one v_readlane away;
 //   4. all threads: hand-over (wtw.py:107-128) and the column bookkeeping up to the next window in closed form
 //      (the same rules as wtw_ctl_body below).
-constexpr int kWinMaxW = 128;
-constexpr int kWinKW = 12;  // code words per lane: 64 + 128 - 1 steps at most
+constexpr int kWinMaxW = 128;   // what the kernel can do (RTS_WTW_WIN=1 forces it up to here)
+constexpr int kWinAutoW = 104;  // what it is chosen for by default
+constexpr int kWinKW = 12;       // code words per lane: 64 + 127 - 1 steps at most
+constexpr int kWinPadFront = 64;  // doubles in front of / behind the cost matrix: lanes that are not on a valid cell read
+constexpr int kWinPadBack = 208;  // (and ignore) whatever their row pointer + step lands on
 
 __host__ __device__ inline int win_ldc(int W) { return (W | 1) + 1; }  // even > W: lanes a row apart hit different LDS banks
 __host__ __device__ inline size_t win_lds_bytes(int W) {
-    const size_t feat = sizeof(double) * (2 * (size_t)W * kWF + 2 * (size_t)W);            // xs, ys, nx, ny
-    const size_t walk = sizeof(uint32_t) * 2 * kWinKW * 64 + sizeof(double) * (size_t)W +  // codes, bottom row of wave 0
+    const size_t feat = sizeof(double) * ((size_t)W * kWF + (size_t)W);                    // xs, nx
+    const size_t walk = sizeof(uint32_t) * 2 * kWinKW * 64 + sizeof(double) * 3 * (size_t)W +  // codes; row 0, column 0, bottom row of wave 0
                         sizeof(int32_t) * 4 * (size_t)W;                                   // sub-path
-    return sizeof(double) * (size_t)W * win_ldc(W) + (feat > walk ? feat : walk) + 128;
+    return sizeof(double) * ((size_t)W * win_ldc(W) + kWinPadFront + kWinPadBack) + feat + walk + 128;
 }
 
-template <int R>
-__global__ void __launch_bounds__(256) wtw_win_kernel(WtwArgs g) {
+#ifdef RTS_WIN_STAMPS
+// diagnostic build only: cycles of wave 0 of stream 0 per phase (load+norms, costs, DP, walk, hand-over), windows
+__device__ long long g_win_stamps[8];
+#define RTS_WIN_STAMP(slot)                                                       \
+    do {                                                                          \
+        const long long now_ = (long long)__builtin_amdgcn_s_memtime();           \
+        if (b == 0 && tid == 0) g_win_stamps[slot] += now_ - stamp_t;             \
+        stamp_t = now_;                                                           \
+    } while (0)
+#else
+#define RTS_WIN_STAMP(slot) \
+    do {                    \
+    } while (0)
+#endif
+
+template <int R, bool STAGE>
+__global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) {
+    constexpr int NT = (R == 1) ? 256 : 512;  // two waves per SIMD for the wide windows: their cost phase is fp64-bound
     extern __shared__ __align__(16) unsigned char wtw_smem[];
     const int W = g.W, ldc = win_ldc(W);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    int32_t *sh = reinterpret_cast<int32_t *>(wtw_smem);                 // [32] control words
-    double *C = reinterpret_cast<double *>(wtw_smem + 128);              // [W][ldc]
-    unsigned char *scratch = reinterpret_cast<unsigned char *>(C + (size_t)W * ldc);
-    // phase 1/2 view of the scratch area
-    double *xs = reinterpret_cast<double *>(scratch);
-    double *ys = xs + (size_t)W * kWF;
-    double *nx = ys + (size_t)W * kWF;
-    double *ny = nx + W;
-    // phase 3/4 view (the features are dead once the costs exist)
-    uint32_t *codes = reinterpret_cast<uint32_t *>(scratch);            // [2][kWinKW][64]
-    double *bot = reinterpret_cast<double *>(codes + 2 * kWinKW * 64);   // [W] bottom row of wave 0
-    int32_t *sub = reinterpret_cast<int32_t *>(bot + W);                 // [2W][2], reversed
+    int32_t *sh = reinterpret_cast<int32_t *>(wtw_smem);                          // [32] control words
+    double *C = reinterpret_cast<double *>(wtw_smem + 128) + kWinPadFront;        // [W][ldc]
+    double *xs = C + (size_t)W * ldc + kWinPadBack;                               // [W][F] live window
+    double *nx = xs + (size_t)W * kWF;                                            // [W]
+    uint32_t *codes = reinterpret_cast<uint32_t *>(nx + W);                       // [2][kWinKW][64]
+    double *row0 = reinterpret_cast<double *>(codes + 2 * kWinKW * 64);           // [W] D[0][:]
+    double *col0 = row0 + W;                                                      // [W] D[:][0]
+    double *bot = col0 + W;                                                       // [W] D[64][:] (wave 0's last row)
+    int32_t *sub = reinterpret_cast<int32_t *>(bot + W);                          // [2W][2], reversed
 
     int32_t *st = g.state + (size_t)b * 8;
     const double *live = g.live + (size_t)b * g.N * kWF;
@@ -335,85 +353,115 @@ __global__ void __launch_bounds__(256) wtw_win_kernel(WtwArgs g) {
         }
         if (!pending) break;
         const int lp = live_ptr, rp = ref_ptr;
-        // ---- 1. features, norms, cost matrix
-        __syncthreads();  // the previous window's walk / hand-over is done with the scratch area
-        for (int idx = tid; idx < n * kWF; idx += 256) xs[idx] = live[(size_t)lp * kWF + idx];
-        for (int idx = tid; idx < m * kWF; idx += 256) ys[idx] = g.ref[(size_t)rp * kWF + idx];
+#ifdef RTS_WIN_STAMPS
+        long long stamp_t = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        // ---- 1. cost matrix.  Lanes own columns (the reference frame and its norm stay in registers), waves share the
+        // rows (the live frame is a wave-uniform LDS read: a broadcast), consecutive lanes store consecutive words.
+        __syncthreads();  // the previous window's walk / hand-over is done with sub[] and the codes
+        for (int idx = tid; idx < n * kWF; idx += NT) xs[idx] = live[(size_t)lp * kWF + idx];
         __syncthreads();
-        for (int i = tid; i < n; i += 256) nx[i] = sqrt(wtw_dot_chain(xs + i * kWF, xs + i * kWF));
-        for (int j = tid; j < m; j += 256) ny[j] = sqrt(wtw_dot_chain(ys + j * kWF, ys + j * kWF));
-        __syncthreads();
-        for (int idx = tid; idx < n * m; idx += 256) {
-            const int i = idx / m, j = idx - i * m;
-            const double dot = wtw_dot_strided(xs + i * kWF, ys + j * kWF);
-            C[(size_t)i * ldc + j] = 1.0 - dot / (nx[i] * ny[j]);  // wtw.py:169
+        for (int i = tid; i < n; i += NT) {
+            double x[kWF];
+#pragma unroll
+            for (int f = 0; f < kWF; f++) x[f] = xs[i * kWF + f];
+            nx[i] = sdp::WtwPolicy::norm(x);
         }
         __syncthreads();
-        // ---- 2. DP: wave r owns rows 64 r .. 64 r + 63
+        RTS_WIN_STAMP(0);
+        for (int j0 = 0; j0 < m; j0 += 64) {
+            const int j = j0 + lane;
+            double y[kWF];
+            sdp::load_frame(g.ref, 1, (long long)rp + (j < m ? j : m - 1), y);
+            const double nyj = sdp::WtwPolicy::norm(y);
+            for (int i = wave; i < n; i += NT / 64) {
+                double x[kWF];
+#pragma unroll
+                for (int f = 0; f < kWF; f++) x[f] = xs[i * kWF + f];
+                const double c = sdp::WtwPolicy::cost(x, nx[i], y, nyj);  // wtw.py:169
+                if (j < m) C[(size_t)i * ldc + j] = c;
+            }
+        }
+        __syncthreads();
+        // row 0 (lane 0) and column 0 (lane 1) of D: running sums in the reference's order (wtw.py:183-198), the costs
+        // fetched 16 at a time so that the LDS latency is paid once per 16 dependent adds
+        if (wave == 0 && lane < 2) {
+            const int cnt = lane == 0 ? m : n;
+            const int stride = lane == 0 ? 1 : ldc;
+            double *out = lane == 0 ? row0 : col0;
+            double acc = 0.0;
+            for (int q0 = 0; q0 < cnt; q0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = C[(size_t)((q0 + q) < cnt ? (q0 + q) : 0) * stride];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    acc = (q0 + q == 0) ? v[q] : acc + v[q];
+                    if (q0 + q < cnt) out[q0 + q] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        if (STAGE) {
+            double *dl = g.dlast + (size_t)b * W * W;
+            for (int q = tid; q < m; q += NT) dl[q] = row0[q];
+            for (int q = tid; q < n; q += NT) dl[(size_t)q * W] = col0[q];
+        }
+        RTS_WIN_STAMP(1);
+        // ---- 2. interior DP: lane l of wave r owns row 1 + 64 r + l, column 1 + t - l at local step t
         {
             const int r = wave;
-            const int rows = (r < R) ? ((n - 64 * r) < 64 ? (n - 64 * r) : 64) : 0;  // <= 0: nothing to do
-            const int T = rows > 0 ? rows + m - 1 : 0;
+            const int nint = n - 1, mint = m - 1;                       // interior rows / columns
+            const int rows = (r < R) ? ((nint - 64 * r) < 64 ? (nint - 64 * r) : 64) : 0;
+            const int T = (rows > 0 && mint > 0) ? rows + mint - 1 : 0;
             const int blocks = (T + 15) >> 4;
-            const int rounds_all = (R == 1) ? ((n + m - 1 + 15) >> 4)
-                                            : (((64 + m - 1 + 15) >> 4) > (5 + ((n - 64 + m - 1 + 15) >> 4)) ? ((64 + m - 1 + 15) >> 4)
-                                                                                                               : (5 + ((n - 64 + m - 1 + 15) >> 4)));
-            const int i = 64 * r + lane;
-            const bool row_ok = lane < rows;
-            double dlast_v = 0.0, du_prev = 0.0;
-            double *dout = g.dlast ? g.dlast + ((size_t)b * W + i) * W : nullptr;
+            const int T0 = (nint > 0 && mint > 0) ? (nint < 64 ? nint : 64) + mint - 1 : 0;
+            const int T1 = (nint > 64 && mint > 0) ? (nint - 64) + mint - 1 : 0;
+            const int rounds0 = (T0 + 15) >> 4, rounds1 = T1 > 0 ? 5 + ((T1 + 15) >> 4) : 0;
+            const int rounds_all = (R == 1 || rounds0 > rounds1) ? rounds0 : rounds1;
+            const int i = 1 + 64 * r + lane;
+            const int ic = i < n ? i : n - 1;
+            // D[i][0] and D[i-1][0]: what the first interior step of this lane sees as `left` and `diag`
+            double dlast_v = col0[ic], du_prev = col0[ic - 1 >= 0 ? ic - 1 : 0];
+            const double *upin = (r == 0) ? row0 : bot;                  // the row above this wave's lane 0
+            double *dout = STAGE ? g.dlast + ((size_t)b * W + ic) * W : nullptr;
+            const double *crow = C + (size_t)ic * ldc + 1 - lane;         // crow[t] = C[i][1 + t - lane]
             for (int k = 0; k < rounds_all; k++) {
                 if (R > 1) lds_barrier();  // wave 1 reads bottom-row values wave 0 wrote at least one round ago
                 const int kb = k - 5 * r;
                 if (kb < 0 || kb >= blocks) continue;  // wave-uniform
-                uint32_t word = 0;
+                // the block's 16 costs and 16 values of the row above lane 0 first (independent of the recurrence: one
+                // LDS round trip per block instead of one per step)
+                double cbuf[16], ubuf[16];
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int t = 16 * kb + q;
-                    const int j = t - lane;
-                    const bool valid = row_ok && j >= 0 && j < m;
-                    const double c = C[valid ? (size_t)i * ldc + j : 0];
-                    double lane0_in = 0.0;
-                    if (R > 1 && r > 0) lane0_in = bot[(t < m) ? t : 0];  // lane 0 of wave 1: (i - 1, j) = wave 0's bottom row
-                    const double du = sdp::shr1(dlast_v, lane0_in);      // D[i-1][j]
-                    const double dl = dlast_v;                            // D[i][j-1]
-                    const double dd = du_prev;                            // D[i-1][j-1]
+                    cbuf[q] = crow[t];
+                    ubuf[q] = upin[(t + 1 < m) ? t + 1 : 0];
+                }
+                uint32_t word = 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int t = 16 * kb + q;  // (steps past T - 1 compute and store nothing anybody reads)
+                    const unsigned jj = (unsigned)(t - lane);            // column - 1
+                    const bool valid = jj < (unsigned)mint && lane < rows;
+                    const double du = sdp::shr1(dlast_v, ubuf[q]);        // D[i-1][j]; lane 0: from LDS
                     double dv;
-                    uint32_t code;
-                    if (i == 0 && j == 0) {
-                        dv = c;
-                        code = 0;
-                    } else if (j == 0) {
-                        dv = du + c;  // wtw.py:187-191
-                        code = 3;
-                    } else if (i == 0) {
-                        dv = dl + c;  // wtw.py:194-198
-                        code = 1;
-                    } else {
-                        double mc = du;  // wtw.py:201-215: up, then left, then diag, strict '<'
-                        code = 3;
-                        if (dl < mc) {
-                            mc = dl;
-                            code = 1;
-                        }
-                        if (dd < mc) {
-                            mc = dd;
-                            code = 2;
-                        }
-                        dv = mc + c;
-                    }
-                    du_prev = du;
+                    int code;
+                    sdp::WtwPolicy::cell(false, false, du, dlast_v, du_prev, cbuf[q], dv, code);  // wtw.py:201-215
+                    du_prev = du;                                          // D[i-1][j-1] of the next step
+                    word |= (uint32_t)code << (2 * q);                     // (codes of cells outside the matrix are never read)
+                    if (t >= lane) dlast_v = dv;                           // D[i][j-1] of the next step; untouched before the lane's first cell
                     if (valid) {
-                        dlast_v = dv;
-                        word |= code << (2 * q);
-                        if (R > 1 && r == 0 && lane == 63) bot[j] = dv;
-                        if (dout) dout[j] = dv;
+                        if (R > 1 && r == 0 && lane == 63) bot[jj + 1] = dv;
+                        if (STAGE) dout[jj + 1] = dv;
                     }
                 }
                 codes[((size_t)r * kWinKW + kb) * 64 + lane] = word;
             }
         }
         __syncthreads();
+        RTS_WIN_STAMP(2);
         // ---- 3. find_path (wtw.py:219-240) by wave 0: sub[] holds the path reversed, sh[0] its length
         if (wave == 0) {
             int i = n - 1, j = m - 1, len = 1;
@@ -423,46 +471,47 @@ __global__ void __launch_bounds__(256) wtw_win_kernel(WtwArgs g) {
             }
             int cur = -1;
             uint32_t cw = 0;
-            while (!(i == 0 && j == 0) && len < 2 * W) {
-                const int r = i >> 6, l = i & 63;
-                const int t = l + j;
-                const int key = r * kWinKW + (t >> 4);
+            while (i > 0 && j > 0) {  // interior cells: the code of (i, j) is bit pair t & 15 of word t >> 4 of lane (i-1) & 63
+                const int l = (i - 1) & 63;
+                const int t = l + j - 1;
+                const int key = ((i - 1) >> 6) * kWinKW + (t >> 4);
                 if (key != cur) {  // uniform
                     cw = codes[(size_t)key * 64 + lane];
                     cur = key;
                 }
                 const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cw, l);
                 const int code = (int)((w >> (2 * (t & 15))) & 3u);
-                if (code == 1)
-                    j -= 1;
-                else if (code == 2) {
-                    i -= 1;
-                    j -= 1;
-                } else
-                    i -= 1;
-                i = __builtin_amdgcn_readfirstlane(i);
-                j = __builtin_amdgcn_readfirstlane(j);
+                i -= (code != sdp::kLeft) ? 1 : 0;   // kUp, kDiag
+                j -= (code != sdp::kUp) ? 1 : 0;     // kLeft, kDiag
                 if (lane == 0) {
                     sub[2 * len] = i;
                     sub[2 * len + 1] = j;
                 }
                 len++;
             }
+            // on row 0 the path runs left, on column 0 up (wtw.py:187-198): the rest is a straight line to (0, 0)
+            const int rest = i + j;  // one of them is 0
+            for (int q = lane; q < rest; q += 64) {
+                sub[2 * (len + q)] = i > 0 ? i - 1 - q : 0;
+                sub[2 * (len + q) + 1] = j > 0 ? j - 1 - q : 0;
+            }
+            len += rest;
             if (lane == 0) {
                 sh[0] = len;
                 sh[1] = 0;
             }
         }
         __syncthreads();
+        RTS_WIN_STAMP(3);
         // ---- 4. hand-over (wtw.py:107-128): l is non-decreasing along the path, so the points with l <= dtw_hop / hop
         // are a prefix of it
         const int len = sh[0];
         int local = 0;
-        for (int f = tid; f < len; f += 256) local += (sub[2 * (len - 1 - f)] <= g.hopf) ? 1 : 0;
+        for (int f = tid; f < len; f += NT) local += (sub[2 * (len - 1 - f)] <= g.hopf) ? 1 : 0;
         if (local) atomicAdd(&sh[1], local);
         __syncthreads();
         const int cnt = sh[1];
-        for (int f = tid; f < cnt; f += 256) {
+        for (int f = tid; f < cnt; f += NT) {
             if (n_path + f < g.path_cap) {
                 path[2 * (size_t)(n_path + f)] = sub[2 * (len - 1 - f)] + lp;
                 path[2 * (size_t)(n_path + f) + 1] = sub[2 * (len - 1 - f) + 1] + rp;
@@ -478,6 +527,10 @@ __global__ void __launch_bounds__(256) wtw_win_kernel(WtwArgs g) {
         n_path += cnt;
         n_windows += 1;
         cells += (long long)n * m;
+        RTS_WIN_STAMP(4);
+#ifdef RTS_WIN_STAMPS
+        if (b == 0 && tid == 0) g_win_stamps[5] += 1;
+#endif
     }
     if (status == RTS_RUNNING && chroma_ptr >= g.N && appended_raw > g.N) status = RTS_LIVE_OVERFLOW;
     if (tid == 0) {
@@ -771,10 +824,12 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     if (const char *e = getenv("RTS_WTW_BIG_FROM")) big_from = atoi(e) < kWtwLdsW ? atoi(e) : kWtwLdsW;
     // Windows of at most 128 frames: the one-launch window kernel (RTS_WTW_WIN=0 or an explicit RTS_WTW_BIG_FROM select the
     // older paths: tests and A/B runs; results are identical).
-    bool win = W <= kWinMaxW;
-    if (const char *e = getenv("RTS_WTW_WIN")) win = win && atoi(e) != 0;
+    // (measured, 64 streams, hop = W / 2: 3.2x faster than the anti-diagonal sweep at W = 20, 3.8x at W = 64, on a par with
+    // the strip DP's launch-per-window rounds at W = 100, behind them from ~110 frames on: kWinAutoW)
+    bool win = W <= kWinAutoW;
+    if (const char *e = getenv("RTS_WTW_WIN")) win = W <= kWinMaxW && atoi(e) != 0;
     if (getenv("RTS_WTW_BIG_FROM")) win = false;
-    h->use_win = win ? (W <= 64 ? 1 : 2) : 0;
+    h->use_win = win ? (W <= 65 ? 1 : 2) : 0;  // interior rows 1 .. W-1: one wave up to 65 frames
     const bool big = !win && W > big_from;
     h->use_big = big;
     if (big) {
@@ -811,9 +866,13 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
         (e = hipMalloc((void **)&h->state, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->path, sizeof(int32_t) * 2 * (size_t)h->path_cap * B)) != hipSuccess ||
         (!big && !win && W > kWtwLdsB && (e = hipMalloc((void **)&h->bwork, (size_t)B * W * W)) != hipSuccess) ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_win_kernel<1>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_win_kernel<1, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_win_kernel<2>),
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_win_kernel<2, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_win_kernel<1, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wtw_win_kernel<2, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess ||
         (big && (e = hipMalloc((void **)&h->ws_sub, sizeof(int32_t) * 4 * (size_t)W * B)) != hipSuccess) ||
         (big && (e = hipMalloc((void **)&h->ws_scr, sizeof(int32_t) * 2 * sdp::scratch_pairs(W, W) * B)) != hipSuccess) ||
@@ -970,9 +1029,15 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
             if (g.fill_separate) hipLaunchKernelGGL(wtw_big_fill_kernel, dim3(128, h->B), dim3(256), 0, s, g);
         }
     } else if (h->use_win == 1) {
-        hipLaunchKernelGGL((wtw_win_kernel<1>), dim3(h->B), dim3(256), h->smem, s, g);
+        if (h->dlast)
+            hipLaunchKernelGGL((wtw_win_kernel<1, true>), dim3(h->B), dim3(256), h->smem, s, g);
+        else
+            hipLaunchKernelGGL((wtw_win_kernel<1, false>), dim3(h->B), dim3(256), h->smem, s, g);
     } else if (h->use_win == 2) {
-        hipLaunchKernelGGL((wtw_win_kernel<2>), dim3(h->B), dim3(256), h->smem, s, g);
+        if (h->dlast)
+            hipLaunchKernelGGL((wtw_win_kernel<2, true>), dim3(h->B), dim3(512), h->smem, s, g);
+        else
+            hipLaunchKernelGGL((wtw_win_kernel<2, false>), dim3(h->B), dim3(512), h->smem, s, g);
     } else if (h->W > kWtwLdsB) {
         hipLaunchKernelGGL((wtw_advance_kernel<false>), dim3(h->B), dim3(kWtwNT), h->smem, s, g);
     } else {
@@ -1024,6 +1089,15 @@ int rts_wtw_read_last_d(rts_wtw *h, int b, double *d_host, void *stream) {
     RTS_HIP(hipStreamSynchronize(s));
     return RTS_OK;
 }
+
+#ifdef RTS_WIN_STAMPS
+/* Diagnostic build only: reads and clears the per-phase cycle sums of wtw_win_kernel (stream 0, wave 0). */
+int rts_wtw_read_win_stamps(long long *out) {
+    static const long long zero[8] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rts::g_win_stamps), sizeof(long long) * 8) != hipSuccess) return -3;
+    return hipMemcpyToSymbol(HIP_SYMBOL(rts::g_win_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int rts_wtw_state_view(rts_wtw *h, int32_t **state_dev) {
     using namespace rts;

@@ -56,10 +56,10 @@ def test_windows_against_reference_vectors(wtw_window_golden, wtw_path):
 
 @pytest.fixture(params=["win", "older"])
 def wtw_path(request, monkeypatch):
-    """Windows of at most 128 frames run on wtw_win_kernel (every window of a push in one launch); RTS_WTW_WIN=0 selects
-    the older kernels (anti-diagonal sweep up to 64 frames, strip DP above), which stay covered this way."""
-    if request.param == "older":
-        monkeypatch.setenv("RTS_WTW_WIN", "0")
+    """Windows of at most 128 frames can run on wtw_win_kernel (every window of a push in one launch; the default up to
+    104 frames, forced up to 128 here); RTS_WTW_WIN=0 selects the older kernels (anti-diagonal sweep up to 64 frames,
+    strip DP above), which stay covered this way."""
+    monkeypatch.setenv("RTS_WTW_WIN", "0" if request.param == "older" else "1")
     return request.param
 
 
