@@ -144,11 +144,15 @@ int rts_otw_device_views(rts_otw *h, int32_t **path_dev, int *path_cap, int32_t 
  * off.  Resets the handle (the matrices are re-initialised on every reset / run). */
 int rts_otw_set_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *stream);
 /* The same matrices on demand, without slowing the tracker down: recomputes them, from everything the handle has
- * consumed since its last reset, into caller-owned double [B][2N][N] buffers (the frames pushed through
- * rts_otw_insert / rts_otw_push are kept by the handle; after rts_otw_run the caller's live buffer is read again
- * and must still be valid).  The handle's own state is not touched, so the streams keep running on the pipelined
- * kernel.  Synchronises `stream`.  What the drop-in classes' .acc_cost / .cost (otw_eran.py:23,27) are made of. */
-int rts_otw_replay_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *stream);
+ * consumed since its last reset, into caller-owned double [B][2N][N] buffers.  Frames that came through rts_otw_insert /
+ * rts_otw_push are kept by the handle: pass live_dev = NULL (live_dtype, T_max, live_len_dev ignored).  Frames of an
+ * rts_otw_run are the caller's memory and the library keeps no pointer to them: pass that call's live_dev, live_dtype,
+ * T_max and live_len_dev again (dtype and T_max are checked against the run being replayed).  The handle's own state is
+ * not touched, so the streams keep running on the pipelined kernel.  Band widths up to 500 (RTS_ERR_UNSUPPORTED above:
+ * only the live bands exist there).  Synchronises `stream`.  What the drop-in classes' .acc_cost / .cost
+ * (otw_eran.py:23,27) are made of. */
+int rts_otw_replay_dense(rts_otw *h, const void *live_dev, int live_dtype, int T_max, const int32_t *live_len_dev,
+                         double *acc_dev, double *cost_dev, void *stream);
 /* Tuning knob, not semantics: waves per stream workgroup (1, 2, 4 or 8; default 8).  Results are identical.
  * With 8 waves and no dense mirror the library runs its pipelined kernel (the next step's strips are computed
  * beside this step's control work); the environment variable RTS_OTW_SPEC=0, read by rts_otw_create, selects

@@ -64,7 +64,7 @@ _decl("rts_otw_read_bands", _i32, [_vp, _i32, _vp, _vp, _vp])
 _decl("rts_otw_device_views", _i32, [_vp, ctypes.POINTER(_vp), _pi32, ctypes.POINTER(_vp)])
 _decl("rts_otw_set_waves", _i32, [_vp, _i32])
 _decl("rts_otw_set_dense", _i32, [_vp, _vp, _vp, _vp])
-_decl("rts_otw_replay_dense", _i32, [_vp, _vp, _vp, _vp])
+_decl("rts_otw_replay_dense", _i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp])
 _decl("rts_otw_kernel_name", ctypes.c_char_p, [_vp])
 _i64 = ctypes.c_longlong
 _decl("rts_dtw_workspace_bytes", _i32, [_i32, _i32, _i32, ctypes.POINTER(ctypes.c_size_t)])

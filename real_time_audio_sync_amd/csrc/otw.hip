@@ -318,6 +318,9 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
     if constexpr (GUARD) {
         const unsigned bA = lds_addr(band + colA), bB = lds_addr(band + colB), dA = lds_addr(Dv + colA), dB = lds_addr(Dv + colB);
         switch (r0) {
+// (One wait behind the join serves all cases.  Waiting inside every case instead costs 2 % of the B = 64 step -- 4.40 vs
+// 4.32 ms, same-call A/B -- so what the single wait relies on, that no case ends with a copy of a register whose LDS
+// data is still in flight, is checked on the built code object: tools/check_lds_waits.py, tests/test_abi.py.)
 #define RTS_CHAIN_LOAD(R)                                                        \
     case R:                                                                      \
         if constexpr (R < L) chain_load<L, R>(bA, bB, dA, dB, prevb, D);         \
@@ -1249,6 +1252,16 @@ __device__ __forceinline__ OtwSettled otw_settle_hit(double *R, double *C, const
     return o;
 }
 
+// The barrier of the pipelined step loops.  The waves of a stream talk to each other through LDS only (bands, cost
+// buffers, plan); what they send to global memory -- wave 0's path points, the dense mirror -- is read by nobody before
+// the launch ends.  __syncthreads() would also drain those stores (a full release: vmcnt(0)) once per step.
+// -DRTS_OTW_FULL_BARRIER restores it for A/B runs.
+#ifdef RTS_OTW_FULL_BARRIER
+#define RTS_STEP_BARRIER() __syncthreads()
+#else
+#define RTS_STEP_BARRIER() ::rts::lds_barrier()
+#endif
+
 template <int W, int NW, bool DENSE, typename RT, bool SPEC>
 __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     static_assert(!SPEC || (NW >= 8 && !DENSE), "the pipelined kernel needs 8 waves and no dense mirror");
@@ -1495,11 +1508,11 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 // reads was made sure of one step ago, and the slots written now are not among it (W >= c + 12)
                 if constexpr (!kNoLiveRing)
                     if (wave == HW0) otw_refill<W, RT>(S, k, e, pt + 3, 0, false);  // the reference has no ring here
-                if (!(pflags & kPlanHit)) __syncthreads();  // this step's chains have read their cost buffers
+                if (!(pflags & kPlanHit)) RTS_STEP_BARRIER();  // this step's chains have read their cost buffers
                 if (!(pflags & kPlanStop))
                     otw_costs_advance<W, RT>(S, e, pt, j0 + (do_col ? 1 : 0), do_row, do_col, tid - 64 * HW0, NHELP);
                 RTS_LW_END(pflags & kPlanHit);
-                __syncthreads();
+                RTS_STEP_BARRIER();
                 sp ^= 1;
             }
         } else if (wave == 1) {
@@ -1514,7 +1527,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                     if ((pflags & (kPlanRow | kPlanCol | kPlanStop)) == (kPlanRow | kPlanCol))  // Both step
                         otw_col_strip<W, DENSE, RT>(S, (pflags & kPlanCi) ? SP.ShC : S.C, a, e, S.Dc[(j0 + 1) & 1], pt,
                                                     j0 + 1, true, sentinel);
-                    __syncthreads();
+                    RTS_STEP_BARRIER();
                 }
                 if ((pflags & (kPlanHit | kPlanRow | kPlanCol)) == (kPlanHit | kPlanRow | kPlanCol)) {
                     // Both step as a hit: the row's last cell (pt, j0) is input of the next speculation; wave 0 writes
@@ -1526,7 +1539,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 if (!(pflags & kPlanStop) && pt + 1 < live_len && pt + 1 < a.live_cap)  // row pt+1 over [.., jn-1]
                     otw_spec_strip<W, false>(S.Dr[(pt + 1) & 1], R, Rsh, jn, c, lane, sentinel, &SP.row[sp ^ 1], RTS_ROUNDS_ACC);
                 RTS_LW_END(pflags & kPlanHit);
-                __syncthreads();
+                RTS_STEP_BARRIER();
                 sp ^= 1;
             }
         } else if (wave == 2) {
@@ -1554,7 +1567,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                             otw_col_strip<W, DENSE, RT>(S, C, a, e, S.Dc[jn & 1], pt, jn, false, sentinel);
                         }
                     }
-                    __syncthreads();
+                    RTS_STEP_BARRIER();
                 }
                 bool drop = false;
                 if ((pflags & (kPlanHit | kPlanRow | kPlanCol)) == (kPlanHit | kPlanRow | kPlanCol)) {
@@ -1569,7 +1582,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 if (!(pflags & kPlanStop) && jn + 1 < N)  // column jn+1 over rows [.., pt-1]
                     otw_spec_strip<W, true>(S.Dc[(jn + 1) & 1], C, Csh, pt, c, lane, sentinel, &SP.col[sp ^ 1], RTS_ROUNDS_ACC, drop);
                 RTS_LW_END(pflags & kPlanHit);
-                __syncthreads();
+                RTS_STEP_BARRIER();
                 sp ^= 1;
             }
         } else {
@@ -1613,7 +1626,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                             otw_col_strip<W, DENSE, RT>(S, C, a, e, S.Dc[jn & 1], pt, jn, false, sentinel);
                     }
                     RTS_STAMP(9);
-                    __syncthreads();
+                    RTS_STEP_BARRIER();
                     RTS_STAMP(10);
                     if constexpr (kThroughput<RT>) {  // the row chain ran on wave 2
                         if (do_row) {
@@ -1647,7 +1660,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 {
                     const long long t0_ = (long long)__builtin_amdgcn_s_memtime();
                     __builtin_amdgcn_s_waitcnt(0xC07F);
-                    __syncthreads();
+                    RTS_STEP_BARRIER();
                     const long long t1_ = (long long)__builtin_amdgcn_s_memtime();
                     __builtin_amdgcn_s_waitcnt(0xC07F);
                     if (pflags & kPlanHit) {
@@ -1662,7 +1675,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                     l_last = t1_;
                 }
 #else
-                __syncthreads();
+                RTS_STEP_BARRIER();
 #endif
                 sp ^= 1;
             }
@@ -1971,9 +1984,9 @@ struct rts_otw {
     const void *attr_fn[8];  // kernel instantiations whose dynamic-LDS limit is already raised on `device`
     // what the handle has consumed since the last reset, for rts_otw_replay_dense
     int src_kind;       // 0 nothing, 1 the buffers of the last rts_otw_run, 2 the handle-owned history, 3 mixed
-    const void *run_live;
-    const int32_t *run_len;
-    int run_dtype, run_T, run_mode;
+    int run_dtype, run_T, run_mode;  // of the last rts_otw_run (the buffers themselves are the caller's and not remembered)
+    int32_t *rp_state, *rp_path;     // scratch state of rts_otw_replay_dense, allocated on first use
+    double *rp_bands;
 };
 
 namespace rts {
@@ -2171,6 +2184,9 @@ int rts_otw_destroy(rts_otw *h) {
     if (h->bands) (void)hipFree(h->bands);
     if (h->hist) (void)hipFree(h->hist);
     if (h->hist_len) (void)hipFree(h->hist_len);
+    if (h->rp_state) (void)hipFree(h->rp_state);
+    if (h->rp_path) (void)hipFree(h->rp_path);
+    if (h->rp_bands) (void)hipFree(h->rp_bands);
     free(h);
     return RTS_OK;
 }
@@ -2204,13 +2220,28 @@ int rts_otw_set_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *strea
     return rts_otw_reset(h, stream);
 }
 
-int rts_otw_replay_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *stream) {
+int rts_otw_replay_dense(rts_otw *h, const void *live_dev, int live_dtype, int T_max, const int32_t *live_len_dev,
+                         double *acc_dev, double *cost_dev, void *stream) {
     using namespace rts;
     if (!h) return set_error(RTS_ERR_INVALID, "handle is NULL");
     if (!acc_dev || !cost_dev) return set_error(RTS_ERR_INVALID, "acc_dev / cost_dev is NULL");
     if (int rc = check_device(h); rc != RTS_OK) return rc;
     if (h->src_kind == 3)
         return set_error(RTS_ERR_UNSUPPORTED, "rts_otw_insert / rts_otw_push after rts_otw_run without a reset: nothing to replay from");
+    // The frames of an rts_otw_run are the caller's: the library does not keep a pointer to memory it does not own, the
+    // caller hands the buffers in again.  Frames that came through rts_otw_insert / rts_otw_push are in the handle's history.
+    if (h->src_kind == 1) {
+        if (!live_dev || !live_len_dev)
+            return set_error(RTS_ERR_INVALID, "the handle's frames came from rts_otw_run: pass that call's live_dev / live_len_dev again");
+        if (live_dtype != RTS_F32 && live_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad live_dtype %d", live_dtype);
+        if (live_dtype != h->run_dtype || T_max != h->run_T)
+            return set_error(RTS_ERR_INVALID, "live_dtype / T_max differ from the rts_otw_run being replayed (%d / %d then)", h->run_dtype, h->run_T);
+    } else if (live_dev) {
+        return set_error(RTS_ERR_INVALID, "the handle's frames came through rts_otw_insert / rts_otw_push (or it is fresh): live_dev must be NULL");
+    }
+    if (h->c > 500)
+        return set_error(RTS_ERR_UNSUPPORTED, "the dense (2N x N) matrices are produced for band widths up to 500 (c=%d): above that only the "
+                                              "two live bands exist (rts_otw_read_bands)", h->c);
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)h->B * h->live_cap * h->N;
     const double sentinel = (h->variant == RTS_VARIANT_OTW) ? 1e10 : (double)INFINITY;
@@ -2218,29 +2249,30 @@ int rts_otw_replay_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *st
     hipLaunchKernelGGL(otw_fill_kernel, dim3(2048), dim3(256), 0, s, cost_dev, n, -1.0);
     RTS_HIP(hipGetLastError());
     if (h->src_kind == 0) return RTS_OK;  // freshly constructed: the matrices are all sentinel (otw_eran.py:23,27)
-    // scratch state so that the handle itself is not disturbed
-    int32_t *state = nullptr, *path = nullptr;
-    double *bands = nullptr;
-    hipError_t e;
-    if ((e = hipMalloc((void **)&state, sizeof(int32_t) * RTS_STATE_LEN * (size_t)h->B)) != hipSuccess ||
-        (e = hipMalloc((void **)&path, sizeof(int32_t) * 2 * (size_t)h->path_cap * h->B)) != hipSuccess ||
-        (e = hipMalloc((void **)&bands, sizeof(double) * 2 * (size_t)(h->c + 1) * h->B)) != hipSuccess) {
-        if (state) (void)hipFree(state);
-        if (path) (void)hipFree(path);
-        return set_error(RTS_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    // scratch state so that the handle itself is not disturbed; allocated on the first replay, kept with the handle
+    if (!h->rp_state) {
+        hipError_t e;
+        if ((e = hipMalloc((void **)&h->rp_state, sizeof(int32_t) * RTS_STATE_LEN * (size_t)h->B)) != hipSuccess ||
+            (e = hipMalloc((void **)&h->rp_path, sizeof(int32_t) * 2 * (size_t)h->path_cap * h->B)) != hipSuccess ||
+            (e = hipMalloc((void **)&h->rp_bands, sizeof(double) * 2 * (size_t)(h->c + 1) * h->B)) != hipSuccess) {
+            if (h->rp_state) (void)hipFree(h->rp_state);
+            if (h->rp_path) (void)hipFree(h->rp_path);
+            h->rp_state = h->rp_path = nullptr;
+            return set_error(RTS_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+        }
     }
-    hipLaunchKernelGGL(otw_reset_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, state, h->B, h->variant);
+    hipLaunchKernelGGL(otw_reset_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, h->rp_state, h->B, h->variant);
     OtwArgs a = base_args(h);
-    a.state = state;
-    a.path = path;
-    a.bands = bands;
+    a.state = h->rp_state;
+    a.path = h->rp_path;
+    a.bands = h->rp_bands;
     a.dense_acc = acc_dev;
     a.dense_cost = cost_dev;
     if (h->src_kind == 1) {
-        a.live = h->run_live;
-        a.live_len = h->run_len;
-        a.live_stride = h->run_T;
-        a.live_f64 = h->run_dtype == RTS_F64;
+        a.live = live_dev;
+        a.live_len = live_len_dev;
+        a.live_stride = T_max;
+        a.live_f64 = live_dtype == RTS_F64;
         a.mode = h->run_mode;
         a.clamp_len = 1;
     } else {
@@ -2251,12 +2283,8 @@ int rts_otw_replay_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *st
         a.mode = RTS_MODE_INSERT_LOOP;
     }
     int rc = launch(h, a, s);
-    const hipError_t es = hipStreamSynchronize(s);
-    (void)hipFree(state);
-    (void)hipFree(path);
-    (void)hipFree(bands);
     if (rc != RTS_OK) return rc;
-    if (es != hipSuccess) return set_error(RTS_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
+    RTS_HIP(hipStreamSynchronize(s));
     return RTS_OK;
 }
 
@@ -2290,8 +2318,6 @@ int rts_otw_run(rts_otw *h, const void *live_dev, int live_dtype, int T_max, con
     a.mode = mode;
     a.clamp_len = 1;
     h->src_kind = 1;
-    h->run_live = live_dev;
-    h->run_len = live_len_dev;
     h->run_dtype = live_dtype;
     h->run_T = T_max;
     h->run_mode = mode;

@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256) wtw_advance_kernel(WtwArgs g) {
 //   4. all threads: hand-over (wtw.py:107-128) and the column bookkeeping up to the next window in closed form
 //      (the same rules as wtw_ctl_body below).
 constexpr int kWinMaxW = 128;   // what the kernel can do (RTS_WTW_WIN=1 forces it up to here)
-constexpr int kWinAutoW = 104;  // what it is chosen for by default
+constexpr int kWinAutoW = 128;  // what it is chosen for by default
 constexpr int kWinKW = 12;       // code words per lane: 64 + 127 - 1 steps at most
 constexpr int kWinPadFront = 64;  // doubles in front of / behind the cost matrix: lanes that are not on a valid cell read
 constexpr int kWinPadBack = 208;  // (and ignore) whatever their row pointer + step lands on

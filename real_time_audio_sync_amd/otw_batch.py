@@ -117,6 +117,7 @@ class BatchedOTW:
     @_on_device
     def reset(self):
         self._version += 1
+        self._keep = None
         nat.check(nat.lib.rts_otw_reset(self._h, self._stream()))
 
     # ---- results ------------------------------------------------------------------------------
@@ -173,7 +174,13 @@ class BatchedOTW:
         (rts_otw_replay_dense); the tracker itself never pays for them."""
         acc = torch.empty((self.B, 2 * self.N, self.N), dtype=torch.float64, device=self.device)
         cost = torch.empty((self.B, 2 * self.N, self.N), dtype=torch.float64, device=self.device)
-        nat.check(nat.lib.rts_otw_replay_dense(self._h, acc.data_ptr(), cost.data_ptr(), self._stream()))
+        if self._keep is not None:   # the frames of the last run(): handed in again, the library keeps no pointer to them
+            lv, ln = self._keep
+            nat.check(nat.lib.rts_otw_replay_dense(self._h, lv.data_ptr(), _np_dtype_code(lv.dtype), int(lv.shape[1]),
+                                                   ln.data_ptr(), acc.data_ptr(), cost.data_ptr(), self._stream()))
+        else:                        # frames that came through insert() / push(): the handle's own history
+            nat.check(nat.lib.rts_otw_replay_dense(self._h, None, nat.F64, 0, None, acc.data_ptr(), cost.data_ptr(),
+                                                   self._stream()))
         return acc, cost
 
     @_on_device

@@ -56,7 +56,7 @@ int main(void) {
     EXPECT(rts_otw_read_bands(NULL, 0, band, band, NULL), RTS_ERR_INVALID);
     EXPECT(rts_otw_device_views(NULL, NULL, NULL, NULL), RTS_ERR_INVALID);
     EXPECT(rts_otw_set_dense(NULL, NULL, NULL, NULL), RTS_ERR_INVALID);
-    EXPECT(rts_otw_replay_dense(NULL, band, band, NULL), RTS_ERR_INVALID);
+    EXPECT(rts_otw_replay_dense(NULL, NULL, RTS_F64, 0, NULL, band, band, NULL), RTS_ERR_INVALID);
     EXPECT(rts_otw_set_waves(NULL, 8), RTS_ERR_INVALID);
 
     /* ---- DTW ---- */

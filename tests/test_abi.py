@@ -54,3 +54,22 @@ def test_no_cpu_fallback_in_product():
             if fn.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, fn
+
+
+def test_no_lds_result_is_used_before_its_wait(nat):
+    """csrc/otw.hip loads through inline-asm ds_read_b64 and waits for them explicitly behind a switch (strip_chain); that
+    is correct only while the register allocator puts no copy of a loaded register in front of the wait.  Checked on the
+    generated code: tools/check_lds_waits.py scans every kernel of the built library."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_lds_waits as chk
+    # the scanner itself: a copy in front of the wait is found, the same code with the wait first is clean
+    head = "0000000000001000 <_Z4demov>:\n"
+    bad = head + "\tds_read_b64 v[4:5], v1 offset:520\n\tv_mov_b32_e32 v9, v4\n\ts_waitcnt lgkmcnt(0)\n\ts_endpgm\n"
+    good = head + "\tds_read_b64 v[4:5], v1 offset:520\n\tds_read_b64 v[6:7], v1\n\ts_waitcnt lgkmcnt(1)\n\tv_mov_b32_e32 v9, v4\n" \
+                  "\ts_waitcnt lgkmcnt(0)\n\tv_add_f64 v[10:11], v[6:7], v[4:5]\n\ts_endpgm\n"
+    late = head + "\tds_read_b64 v[4:5], v1\n\tds_read_b64 v[6:7], v1\n\ts_waitcnt lgkmcnt(1)\n\tv_mov_b32_e32 v9, v7\n\ts_endpgm\n"
+    assert len(chk.check(bad)[2]) == 1 and len(chk.check(good)[2]) == 0 and len(chk.check(late)[2]) == 1
+    kernels, loads, violations = chk.check(chk.disassemble(nat.SO_PATH))
+    assert kernels >= 50 and loads >= 5000      # every instantiation of every kernel was looked at
+    assert not violations, violations[:5]

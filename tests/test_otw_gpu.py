@@ -411,7 +411,9 @@ def test_bands_wider_than_500_cells(gpu):
         drop.insert(lives[0][:, f])
         o.insert(lives[0][:, f])
     assert np.array_equal(np.asarray(drop.path), o.path)
-    with pytest.raises(nat.RtsyncError, match="dense"):  # the dense mirror stops at c = 500
+    with pytest.raises(NotImplementedError, match="bands"):  # the dense mirror stops at c = 500: the drop-in says so up front
         drop.acc_cost
+    with pytest.raises(nat.RtsyncError, match="dense"):      # ... and so does the C-ABI
+        drop._eng.replay_dense()
     with pytest.raises(nat.RtsyncError):
         ob.BatchedOTW(ref, 1013, 3, batch=1, dtype=torch.float32)
