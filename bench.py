@@ -76,7 +76,7 @@ def oracle_paths(ref, lives, c, mrc, procs):
         return [r[2] for r in pool.map(_cpu_worker, tasks, chunksize=1)]
 
 
-def cpu_legs(ref, lives, c, mrc, n_cpu, numpy_leg=True):
+def cpu_legs(ref, lives, c, mrc, n_cpu, numpy_leg=True, allow_fork=True):
     """The CPU baseline legs.  Must run before anything touches the GPU (it forks)."""
     import multiprocessing as mp
     import oracle
@@ -90,7 +90,7 @@ def cpu_legs(ref, lives, c, mrc, n_cpu, numpy_leg=True):
     legs = {"c_port_1core": {"value": frames1 / secs1, "unit": "frames/s", "cores": 1,
                              "sample": "%d streams, %d frames, one after another" % (n_cpu, frames1)}}
     # all usable cores, one stream per task; the rate is frames / the busiest worker's time in the insert loop
-    procs = min(n_cpu, usable_cpus())
+    procs = min(n_cpu, usable_cpus()) if allow_fork else 1
     if procs > 1:
         with mp.get_context("fork").Pool(procs) as pool:
             pool.map(_cpu_worker, tasks[:procs], chunksize=1)  # warm every worker (library load, first touch)
@@ -230,16 +230,22 @@ def _otw_alg_bytes(states, nat):
     return 4 * cells + 48 * frames + 48 * n_col + 8 * n_path, frames, cells, n_col, n_path
 
 
-def secondary_gpu(inp, cpu, dev, head_ref, head_lives, head_paths, c, mrc):
-    """The other BASELINE configs on the same box, device time from HIP events on the launch stream (median of 5)."""
+def secondary_gpu(inp, cpu, dev, head_ref, head_lives, head_paths, c, mrc, only=None):
+    """The other BASELINE configs on the same box, device time from HIP events on the launch stream (median of 5).
+    `only`: set of entry keys to run (profiling: tools/collect_profile.py traces one entry per rocprofv3 run)."""
     import torch
     from real_time_audio_sync_amd import _native as nat
     from real_time_audio_sync_amd import chroma, dtw, otw_batch, wtw
     from real_time_audio_sync_amd.otw_batch import frames_tensor
     out = []
 
+    def wanted(key):
+        return only is None or key in only
+
     # ---- configs[0]: offline DTW on two 30 s clips (322 frames at hop 2048, 1289 at hop 512), one pair
     for key in ("dtw322", "dtw1289"):
+        if not wanted(key):
+            continue
         a, b = inp[key]
         ad, bd = frames_tensor(a, dev, torch.float32), frames_tensor(b, dev, torch.float32)
         ms = _timed(lambda: dtw.dtw_batch(ad, bd, want_back=False))
@@ -248,88 +254,101 @@ def secondary_gpu(inp, cpu, dev, head_ref, head_lives, head_paths, c, mrc):
         ok = n > 0 and np.array_equal(path[0, :n].cpu().numpy(), cpu[key]["path"]) and _sha(acc[0].cpu().numpy()) == cpu[key]["acc_sha"]
         cells = a.shape[1] * b.shape[1]
         out.append(_entry("configs[0]: dtw.DTW %d x %d, one pair (cost + strip DP + backtrack)" % (a.shape[1], b.shape[1]),
-                          ms, cells * 16.25, {"path_and_acc_equal_c_port": bool(ok)}, cpu_port_ms=cpu[key]["ms"], cpu_cores=1,
+                          ms, cells * 16.25, {"path_and_acc_equal_c_port": bool(ok)}, key=key, cpu_port_ms=cpu[key]["ms"], cpu_cores=1,
+                          kernels=["dtw_cost_kernel", "dtw_prep_kernel", "dtw_sdp_kernel", "dtw_tail_kernel"],
                           bytes_per_unit="16.25 B per cell: 8 cost + 8 acc + 2 bits of step code"))
 
     # ---- configs[1]: single-stream OTW c=500 (stream 0 of the headline batch), and the batch with float64 features
-    for name, B, tdt in (("configs[1]: single-stream OTW c=%d (stream 0 of the batch), f32 features" % c, 1, torch.float32),
-                         ("configs[2] with float64 features in HBM (what wav_to_chroma produces)", len(head_lives), torch.float64)):
+    for key, name, B, tdt in (("otw_b1", "configs[1]: single-stream OTW c=%d (stream 0 of the batch), f32 features" % c, 1, torch.float32),
+                              ("otw_b64_f64", "configs[2] with float64 features in HBM (what wav_to_chroma produces)", len(head_lives), torch.float64)):
+        if not wanted(key):
+            continue
         eng = otw_batch.BatchedOTW(head_ref, c, mrc, batch=B, dtype=tdt, device=dev)
         lv, ln = eng.pack(head_lives[:B])
         ms = _timed(lambda: eng.run(lv, ln))
         st = eng.states()
         alg, frames, _, _, _ = _otw_alg_bytes(st, nat)
         bad = sum(0 if np.array_equal(eng.path(b), head_paths[b]) else 1 for b in range(B)) if head_paths else None
-        out.append(_entry(name, ms, alg, {"streams_checked": B if head_paths else 0, "path_mismatches": bad},
-                          frames=frames, frames_per_s=frames / (ms * 1e-3)))
+        out.append(_entry(name, ms, alg, {"streams_checked": B if head_paths else 0, "path_mismatches": bad}, key=key,
+                          kernels=["otw_reset_kernel", "otw_advance_kernel"], frames=frames, frames_per_s=frames / (ms * 1e-3)))
         eng.close()
 
     # ---- chroma front end: 30 minutes of audio -> 19 379 frames (configs[4]'s reference length)
-    plan = chroma.ChromaPlan(4096, 2048, 22050, dev)
-    wav = torch.from_numpy(inp["audio"]).to(dev)
-    m = plan.num_frames(wav.numel(), 2048)
-    ms = _timed(lambda: plan.frames(wav, pad_left=2048))
-    got = plan.frames(wav, pad_left=2048)[0].cpu().numpy()
-    worst = 0.0
-    for m0, want in cpu["chroma"]["want"].items():
-        worst = max(worst, float(np.abs(got[m0:m0 + want.shape[1]].T - want).max()))
-    out.append(_entry("chroma.wav_to_chroma: 30 min of audio, fft 4096 / hop 2048, %d frames" % m, ms, m * (2048 * 4 + 96),
-                      {"frames_checked": cpu["chroma"]["frames"], "max_abs_diff_vs_numpy_oracle": worst, "tolerance": 1e-11,
-                       "ok": bool(worst <= 1e-11)},
-                      cpu_port_ms=cpu["chroma"]["ms_per_frame"] * m, cpu_cores=1,
-                      cpu_sample="numpy oracle on %d frames, scaled to %d" % (cpu["chroma"]["frames"], m),
-                      frames_per_s=m / (ms * 1e-3), bytes_per_unit="8 KB of new float32 samples + 96 B chroma per frame"))
-    plan.close()
-    del wav
+    if wanted("chroma"):
+        plan = chroma.ChromaPlan(4096, 2048, 22050, dev)
+        wav = torch.from_numpy(inp["audio"]).to(dev)
+        m = plan.num_frames(wav.numel(), 2048)
+        ms = _timed(lambda: plan.frames(wav, pad_left=2048))
+        got = plan.frames(wav, pad_left=2048)[0].cpu().numpy()
+        worst = 0.0
+        for m0, expect in cpu["chroma"]["want"].items():
+            worst = max(worst, float(np.abs(got[m0:m0 + expect.shape[1]].T - expect).max()))
+        out.append(_entry("chroma.wav_to_chroma: 30 min of audio, fft 4096 / hop 2048, %d frames" % m, ms, m * (2048 * 4 + 96),
+                          {"frames_checked": cpu["chroma"]["frames"], "max_abs_diff_vs_numpy_oracle": worst, "tolerance": 1e-11,
+                           "ok": bool(worst <= 1e-11)}, key="chroma", kernels=["chroma_frames4096_kernel"],
+                          cpu_port_ms=cpu["chroma"]["ms_per_frame"] * m, cpu_cores=1,
+                          cpu_sample="numpy oracle on %d frames, scaled to %d" % (cpu["chroma"]["frames"], m),
+                          frames_per_s=m / (ms * 1e-3), bytes_per_unit="8 KB of new float32 samples + 96 B chroma per frame"))
+        plan.close()
+        del wav
 
     # ---- WTW, 64 streams, at the reference's two window settings: W=20/hop=10 (tests.py:174), W=100/hop=50 (wtw_live.py)
-    ref, lives = inp["wtw64"]
-    refd = torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev)
-    tmax = max(l.shape[1] for l in lives)
-    cols = np.zeros((len(lives), tmax, 12))
-    for i, l in enumerate(lives):
-        cols[i, :l.shape[1]] = l.T
-    cols_d = torch.from_numpy(cols).to(dev)
-    n_new = torch.tensor([l.shape[1] for l in lives], dtype=torch.int32, device=dev)
-    for W, hopf in ((20, 10), (100, 50)):
-        eng = wtw.BatchedWTW(refd, W, hopf, len(lives))
+    if wanted("wtw20") or wanted("wtw100"):
+        ref, lives = inp["wtw64"]
+        refd = torch.from_numpy(np.ascontiguousarray(ref.T)).to(dev)
+        tmax = max(l.shape[1] for l in lives)
+        cols = np.zeros((len(lives), tmax, 12))
+        for i, l in enumerate(lives):
+            cols[i, :l.shape[1]] = l.T
+        cols_d = torch.from_numpy(cols).to(dev)
+        n_new = torch.tensor([l.shape[1] for l in lives], dtype=torch.int32, device=dev)
+        for W, hopf in ((20, 10), (100, 50)):
+            if not wanted("wtw%d" % W):
+                continue
+            eng = wtw.BatchedWTW(refd, W, hopf, len(lives))
 
-        def run_wtw():
-            eng.reset()
-            eng.push(cols_d, n_new, precheck=True)
-        ms = _timed(run_wtw)
-        st = eng.states()
-        windows = int(st[:, 5].sum())
-        frames = int(st[:, 0].sum())
-        bad = sum(0 if np.array_equal(eng.path(b), cpu["wtw%d" % W]["paths"][b]) else 1 for b in range(len(lives)))
-        out.append(_entry("wtw.WTW: %d streams, W=%d frames / hop=%d, ref 2200 frames" % (len(lives), W, hopf), ms,
-                          windows * (2 * W * W + 96 * W), {"streams_checked": len(lives), "path_mismatches": bad},
-                          cpu_port_ms=cpu["wtw%d" % W]["ms"], cpu_cores=1, windows=windows, frames=frames,
-                          frames_per_s=frames / (ms * 1e-3), bytes_per_unit="2 W^2 + 96 W per window (SURVEY 8(d))"))
-        eng.close()
+            def run_wtw():
+                eng.reset()
+                eng.push(cols_d, n_new, precheck=True)
+            ms = _timed(run_wtw)
+            st = eng.states()
+            windows = int(st[:, 5].sum())
+            frames = int(st[:, 0].sum())
+            bad = sum(0 if np.array_equal(eng.path(b), cpu["wtw%d" % W]["paths"][b]) else 1 for b in range(len(lives)))
+            out.append(_entry("wtw.WTW: %d streams, W=%d frames / hop=%d, ref 2200 frames" % (len(lives), W, hopf), ms,
+                              windows * (2 * W * W + 96 * W), {"streams_checked": len(lives), "path_mismatches": bad},
+                              key="wtw%d" % W, kernels=["wtw_append_kernel", "wtw_win_kernel"],
+                              cpu_port_ms=cpu["wtw%d" % W]["ms"], cpu_cores=1, windows=windows, frames=frames,
+                              frames_per_s=frames / (ms * 1e-3), bytes_per_unit="2 W^2 + 96 W per window (SURVEY 8(d))",
+                              includes="handle reset (three memsets) + append + every window of every stream in one launch"))
+            eng.close()
 
     # ---- configs[4]: one W = 10 000 window against the 30-minute reference
-    ref5, live5 = inp["wtw10k"]
-    eng = wtw.BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref5.T)).to(dev), 10000, 5000, 1)
-    c5 = torch.from_numpy(np.ascontiguousarray(live5.T))[None].to(dev)
+    if wanted("wtw10k"):
+        ref5, live5 = inp["wtw10k"]
+        eng = wtw.BatchedWTW(torch.from_numpy(np.ascontiguousarray(ref5.T)).to(dev), 10000, 5000, 1)
+        c5 = torch.from_numpy(np.ascontiguousarray(live5.T))[None].to(dev)
 
-    def run5():
-        eng.reset()
-        eng.push(c5, precheck=True)
-    ms = _timed(run5, reps=5, warm=1)
-    s5 = eng.state()
-    p5 = eng.path()
-    gold = cpu["wtw10k"]
-    par = {"windows": s5["windows"], "path_len": int(len(p5)), "path_sha256": _sha(p5.astype(np.int32))}
-    if gold:
-        par["equal_to_fixture"] = bool(par["path_sha256"] == gold["path_sha256"] and par["path_len"] == gold["path_len"])
-        par["fixture"] = "tests/golden/wtw10k_golden.json (%s)" % gold.get("made_by", "?")
-    out.append(_entry("configs[4]: wtw.WTW long-form, ref 19 380 frames, one window of W=10 000 frames (float64, not the "
-                      "config's fp16 band)", ms / max(s5["windows"], 1), 2 * 10000 * 10000 + 96 * 10000, par,
-                      cpu_port_ms=gold.get("c_port_ms") if gold else None, cpu_cores=1,
-                      cpu_sample="one window through the C port when the fixture was made (build container)",
-                      bytes_per_unit="2 W^2 + 96 W per window (SURVEY 8(d))"))
-    eng.close()
+        def run5():
+            eng.reset()
+            eng.push(c5, precheck=True)
+        ms = _timed(run5, reps=5, warm=1)
+        s5 = eng.state()
+        p5 = eng.path()
+        gold = cpu["wtw10k"]
+        par = {"windows": s5["windows"], "path_len": int(len(p5)), "path_sha256": _sha(p5.astype(np.int32))}
+        if gold:
+            par["equal_to_fixture"] = bool(par["path_sha256"] == gold["path_sha256"] and par["path_len"] == gold["path_len"])
+            par["fixture"] = "tests/golden/wtw10k_golden.json (%s)" % gold.get("made_by", "?")
+        out.append(_entry("configs[4]: wtw.WTW long-form, ref 19 380 frames, one window of W=10 000 frames (float64, not the "
+                          "config's fp16 band)", ms / max(s5["windows"], 1), 2 * 10000 * 10000 + 96 * 10000, par, key="wtw10k",
+                          kernels=["wtw_big_ctl_kernel", "wtw_big_fill_kernel", "wtw_big_dp_kernel", "wtw_big_hops_kernel",
+                                   "wtw_big_segment_kernel"],
+                          cpu_port_ms=gold.get("c_port_ms") if gold else None, cpu_cores=1,
+                          cpu_sample="one window through the C port when the fixture was made (build container); the "
+                                     "reference's own Python took %.0f s there" % (gold.get("reference_s", float("nan")) if gold else float("nan")),
+                          bytes_per_unit="2 W^2 + 96 W per window (SURVEY 8(d))"))
+        eng.close()
     return out
 
 
@@ -349,6 +368,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline / parity gate / secondary (profiling runs)")
     ap.add_argument("--no-numpy", action="store_true", help="skip the (slow) numpy leg of cpu_baseline")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--secondary-only", default="", help="comma-separated secondary entry keys (dtw322, dtw1289, otw_b1, "
+                    "otw_b64_f64, chroma, wtw20, wtw100, wtw10k): run only those (profiling, one entry per rocprofv3 run)")
+    ap.add_argument("--no-fork", action="store_true", help="CPU legs without worker processes (1-core leg only): safe "
+                    "under rocprofv3, whose preloaded runtime must not be forked")
     ap.add_argument("--single-process", action="store_true",
                     help="one host process drives all --gpus devices through shard.ShardedOTW (no torch.distributed)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "otw_traffic.json"),
@@ -395,7 +418,7 @@ def main():
     if not args.no_cpu:
         if n_gpus == 1:
             n_cpu = B if args.cpu_streams < 0 else min(B, args.cpu_streams)
-            cpu = cpu_legs(ref, lives, args.c, args.max_run_count, n_cpu, numpy_leg=not args.no_numpy)
+            cpu = cpu_legs(ref, lives, args.c, args.max_run_count, n_cpu, numpy_leg=not args.no_numpy, allow_fork=not args.no_fork)
             opaths = cpu[1]
         else:
             opaths = oracle_paths(ref, lives, args.c, args.max_run_count, max(1, usable_cpus() // max(local_world, 1)))
@@ -582,7 +605,8 @@ def main():
     # ---- secondary workloads (N = 1): after the timed headline, on the same device
     if result is not None and want_secondary:
         t_sec = time.perf_counter()
-        result["secondary"] = secondary_gpu(sec_inp, sec_cpu, dev, ref, lives, opaths, args.c, args.max_run_count)
+        only = set(k for k in args.secondary_only.split(",") if k) or None
+        result["secondary"] = secondary_gpu(sec_inp, sec_cpu, dev, ref, lives, opaths, args.c, args.max_run_count, only)
         result["secondary_wall_s"] = time.perf_counter() - t_sec
     if rank == 0:
         print(json.dumps(result))

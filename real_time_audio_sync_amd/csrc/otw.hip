@@ -1486,6 +1486,14 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     __syncthreads();
 
     int sp = 0;  // pipelined kernel: step parity (plan slot read this step; speculation results go to [sp ^ 1])
+#ifdef RTS_OTW_PRIO_W0
+    // experiment (profiles/experiments/README.md): the waves that pace a step -- control wave 0, chain waves 1 / 2 -- each
+    // share a SIMD with a helper wave; a static priority lets them win every issue arbitration
+    if constexpr (SPEC) {
+        if (wave == 0) __builtin_amdgcn_s_setprio(RTS_OTW_PRIO_W0);
+        if (wave == 1 || wave == 2) __builtin_amdgcn_s_setprio(RTS_OTW_PRIO_W12);
+    }
+#endif
     if constexpr (SPEC) {
         // ---- pipelined step loops.  While wave 0 runs the control work of a step, wave 1 already runs the row strip
         // the next step needs if it turns out Row-only and wave 2 the column strip it needs if it turns out
@@ -1612,6 +1620,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 stamp_base = (pflags & kPlanHit) ? 0 : 8;
                 if (stamp_base) stamp_sum[14] += 1; else stamp_sum[6] += 1;
 #endif
+                if (pflags & kPlanHit) RTS_STAMP(1);  // (diagnostic: the step's entry -- plan words, buffer selection -- apart from settle)
                 if ((pflags & kPlanHit) && do_row && do_col) {
                     o = otw_settle_hit_both<W, RT>(R, C, &SP.row[sp], &SP.col[sp], k, e, pt, j0, sentinel);
                 } else if (pflags & kPlanHit) {

@@ -1,7 +1,7 @@
 #!/bin/bash
-# One pass over everything profiles/<tag>_* holds (run on the GPU box: gpurun -- bash tools/collect_all.sh r02b).
+# One pass over everything profiles/<tag>_* holds (run on the GPU box: gpurun -- bash tools/collect_all.sh r03a; build tools/_diag/librtsync_diag.so with RTS_DIAG_LEVEL=2 python tools/otw_phase_profile.py --build first).
 set -e
-TAG=${1:-r02b}
+TAG=${1:-r03a}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
@@ -15,4 +15,9 @@ done
 timeout -k 10 300 python3 bench.py --dtype f64 --no-numpy > $OUT/${TAG}_bench_f64.json
 timeout -k 10 300 python3 bench.py --dtype f64 --no-cpu --batch 4096 --steps 5 --warmup 2 >> $OUT/${TAG}_batch_sweep.jsonl
 timeout -k 10 600 python3 tools/bench_secondary.py > $OUT/${TAG}_secondary_kernels.jsonl 2> $OUT/secondary.err || { tail -20 $OUT/secondary.err; exit 1; }
+timeout -k 10 300 python3 tools/bench_live.py 120 > $OUT/${TAG}_live.jsonl 2> $OUT/live.err || { tail -20 $OUT/live.err; exit 1; }
+timeout -k 10 300 python3 tools/bench_wtw.py 20 64 100 128 > $OUT/${TAG}_wtw_paths.jsonl 2> $OUT/wtw.err || { tail -20 $OUT/wtw.err; exit 1; }
+if [ -f tools/_diag/librtsync_diag.so ]; then
+  RTS_DIAG_LEVEL=2 timeout -k 10 200 python3 tools/otw_phase_profile.py > $OUT/${TAG}_phase_light.txt 2>/dev/null || true
+fi
 echo collected

@@ -6,12 +6,16 @@
   1. bench.py (default flags)                                   -> TAG_bench_final.json
   2. rocprofv3 --kernel-trace --stats -- python3 bench.py ...   -> TAG_otw_kernel_stats.csv, TAG_bench_under_rocprof.json
   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes, --no-cpu, 3 steps)
-                                                                -> TAG_pmc.json, otw_traffic.json
+                                                                -> TAG_pmc.json, otw_traffic.json (with the sha of csrc/otw.hip)
+  4. per secondary entry of the bench line: rocprofv3 --kernel-trace --stats -- python3 bench.py --secondary-only KEY ...
+                                                                -> TAG_secondary_kernel_stats.json
 Every profiler pass is its own child process with the program right after `--` (no shell, no env wrapper).
-Copy what should be judged from gpurun_out/profile_TAG/ into profiles/.
+Everything is written under gpurun_out/profile_TAG/ only; copy what should be judged into profiles/ by hand
+(profiles/otw_traffic.json included: bench.py reports it as roofline.traffic only while its otw_hip_sha16 matches).
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import subprocess
@@ -85,6 +89,7 @@ def main():
         pmc.update(v)
         n.update(c)
     traffic = {
+        "otw_hip_sha16": hashlib.sha256(open(os.path.join(ROOT, "real_time_audio_sync_amd", "csrc", "otw.hip"), "rb").read()).hexdigest()[:16],
         "hbm_bytes_per_launch": int((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024),
         "FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"],
         "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024  -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per "
@@ -94,10 +99,10 @@ def main():
                   "kernel %s, %s (tools/collect_profile.py)" % (krow["Name"], tag)}
     # the un-profiled bench line last, reading the traffic figure this very pass measured (bench.py takes
     # roofline.traffic from profiles/otw_traffic.json), so that the two files agree
-    for path in (os.path.join(out, "otw_traffic.json"), os.path.join(ROOT, "profiles", "otw_traffic.json")):
-        with open(path, "w") as f:
-            json.dump(traffic, f, indent=1)
-    final = run(["python3", "bench.py"], os.path.join(out, tag + "_bench_final.json"))
+    with open(os.path.join(out, "otw_traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+    final = run(["python3", "bench.py", "--traffic-json", os.path.join(out, "otw_traffic.json")],
+                os.path.join(out, tag + "_bench_final.json"))
     print("bench: %.3f ms/step, %.3e frames/s" % (final["ms_per_step"], final["value"]), flush=True)
     summary = {"kernel": krow["Name"], "kernel_trace": {k: krow[k] for k in ("Calls", "AverageNs", "MinNs", "MaxNs", "StdDev")},
                "pmc_mean_per_dispatch": pmc, "pmc_dispatches": n,
@@ -106,7 +111,34 @@ def main():
     with open(os.path.join(out, tag + "_pmc.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary["pmc_mean_per_dispatch"], indent=1))
+    bench_secondary(tag, out, final)
     secondary(tag, out)
+
+
+def bench_secondary(tag, out, final):
+    """Kernel statistics of every secondary entry of the bench line, one rocprofv3 run per entry, next to the entry's own
+    HIP-event figure from that run and from the un-profiled bench line."""
+    rows = []
+    plain = {e["key"]: e for e in final.get("secondary", [])}
+    for key in ("dtw322", "dtw1289", "otw_b1", "otw_b64_f64", "chroma", "wtw20", "wtw100", "wtw10k"):
+        d = os.path.join(out, "trace_sec_" + key)
+        line = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py",
+                    "--no-fork", "--no-numpy", "--steps", "2", "--warmup", "1", "--secondary-only", key],
+                   os.path.join(out, "sec_%s.json" % key))
+        entry = [e for e in line["secondary"] if e["key"] == key][0]
+        want = [k.split(" ")[0] for k in entry["kernels"]]
+        ks = []
+        with open(find(d, "kernel_stats.csv")) as f:
+            for r in csv.DictReader(f):
+                if any(w in r["Name"] for w in want) and not (key != "otw_b64_f64" and key != "otw_b1" and "otw_" in r["Name"]):
+                    ks.append({"name": r["Name"][:120], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                               "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3})
+        rows.append({"key": key, "workload": entry["workload"], "ms_hip_events_under_rocprof": entry["ms"],
+                     "ms_hip_events_plain_bench": plain.get(key, {}).get("ms"), "kernels": ks})
+        print("secondary %-12s %.4f ms (plain %.4f)  %s" % (key, entry["ms"], plain.get(key, {}).get("ms") or float("nan"),
+                                                           ", ".join("%s x%d %.1f us" % (k["name"].split("(")[0][-28:], k["calls"], k["avg_us"]) for k in ks)), flush=True)
+    with open(os.path.join(out, tag + "_secondary_kernel_stats.json"), "w") as f:
+        json.dump(rows, f, indent=1)
 
 
 def kernel_rows(stats_csv, names):
@@ -128,7 +160,7 @@ def secondary(tag, out):
         f.write("".join(l + "\n" for l in p.stdout.splitlines() if l.startswith("{")))
     stats = find(d, "kernel_stats.csv")
     keep = ("sdp_kernel", "big_dp", "big_ctl", "big_hops", "big_segment", "dtw_hops", "dtw_segment", "dtw_cost", "dtw_prep",
-            "chroma_frames", "wtw_advance", "_tail_kernel", "tail_ctl", "big_fill")
+            "chroma_frames", "wtw_advance", "wtw_win", "_tail_kernel", "tail_ctl", "big_fill")
     with open(stats) as f, open(os.path.join(out, tag + "_sdp_kernel_stats.csv"), "w") as g:
         for i, line in enumerate(f):
             if i == 0 or any(k in line for k in keep):

@@ -70,7 +70,7 @@ def main():
             steps = max(d[:, 2].sum() + d[:, 5].sum(), 1)
             print("extra carry rounds per speculative chain: row %.2f, column %.2f" % (d[:, 13].sum() / steps, d[:, 14].sum() / steps))
             return
-        nm = ["barrier-2 wait", "phase A (chain / install)", "barrier-1 wait", "settle", "decide", "plan + refill"]
+        nm = ["barrier-2 wait", "phase A (chain / install) | hit: step entry", "barrier-1 wait", "settle", "decide", "plan + refill"]
         for base, label in ((0, "hit steps"), (8, "other steps")):
             n = d[:, base + 6].sum()
             tot = d[:, base:base + 6].sum()
