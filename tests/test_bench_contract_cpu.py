@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r02b_bench_final.json, produced by `python bench.py` on an MI355X)
+"""The committed bench line (profiles/r03a_bench_final.json, produced by `python bench.py` on an MI355X)
 carries every field the driver's contract asks for, and its numbers are self-consistent."""
 import json
 import os
@@ -7,7 +7,7 @@ from conftest import ROOT
 
 
 def test_bench_line_contract():
-    r = json.load(open(os.path.join(ROOT, "profiles", "r02b_bench_final.json")))
+    r = json.load(open(os.path.join(ROOT, "profiles", "r03a_bench_final.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert r["metric"] == base["metric"] and r["unit"] == "frames/s"
     for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -34,4 +34,19 @@ def test_bench_line_contract():
     assert legs["c_port_1core"]["cores"] == 1 and legs["numpy_1core"]["cores"] == 1 and legs["numpy_1core"]["path_equals_c_port"]
     assert cb["cores"] == legs["c_port_allcores"]["cores"] >= 2 and cb["value"] == legs["c_port_allcores"]["value"]
     assert legs["c_port_allcores"]["value"] > legs["c_port_1core"]["value"] > legs["numpy_1core"]["value"]
-    assert r["parity"]["path_mismatches"] == 0 and r["parity"]["streams_checked"] == 64
+    assert r["parity"]["path_mismatches"] == 0 and r["parity"]["streams_checked"] == r["parity"]["streams_total"] == 64
+    # provenance of the counter figure and of the clock (round-2 review): labelled, and tied to the kernel source
+    ts = rf["traffic_source"]
+    assert ts["measured_in_this_run"] is False and ts["kernel_source_sha16"] == ts["kernel_source_sha16_now"]
+    assert "assumed" in lm["f_clk_source"]
+    # the other BASELINE configs ride in the same line, each with its parity verdict and its roofline fraction
+    sec = {e["key"]: e for e in r["secondary"]}
+    assert set(sec) == {"dtw322", "dtw1289", "otw_b1", "otw_b64_f64", "chroma", "wtw20", "wtw100", "wtw10k"}
+    for e in sec.values():
+        assert e["ms"] > 0 and e["algorithmic_bytes"] > 0 and abs(e["frac"] - e["algorithmic_bytes"] / (e["ms"] * 1e-3) / 1e9 / 8000.0) < 1e-6 * e["frac"]
+    assert sec["dtw322"]["parity"]["path_and_acc_equal_c_port"] and sec["dtw1289"]["parity"]["path_and_acc_equal_c_port"]
+    assert sec["dtw322"]["cpu_port_ms"] > 0 and sec["dtw1289"]["cpu_port_ms"] > sec["dtw322"]["cpu_port_ms"]
+    for k in ("otw_b1", "otw_b64_f64", "wtw20", "wtw100"):
+        assert sec[k]["parity"]["path_mismatches"] == 0 and sec[k]["parity"]["streams_checked"] >= 1
+    assert sec["chroma"]["parity"]["ok"] and sec["wtw10k"]["parity"]["equal_to_fixture"]
+    assert r["secondary_wall_s"] < 60
