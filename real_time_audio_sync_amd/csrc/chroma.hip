@@ -230,15 +230,9 @@ __global__ void __launch_bounds__(kChromaWG) chroma_frames_kernel(ChromaArgs g) 
                                  : (void *)(reinterpret_cast<float *>(g.chroma_out) + oo);
     }
 
-    // this thread's window coefficients (sample pairs n = tid + r*256) stay in registers for every frame
+    // (the window coefficients are read from the L2-resident table where they are used: keeping 16 of them per thread in
+    // registers, next to the prefetched samples, pushed this kernel into scratch -- 176 B per lane with float64 samples)
     constexpr int kMaxPairs = 8;  // N2/256 <= 8 for L <= 4096
-    double win_re[kMaxPairs], win_im[kMaxPairs];
-#pragma unroll
-    for (int r = 0; r < kMaxPairs; r++) {
-        const int n = tid + r * kChromaNT;
-        win_re[r] = (n < N2) ? g.window[2 * n] : 0.0;
-        win_im[r] = (n < N2) ? g.window[2 * n + 1] : 0.0;
-    }
 
     // Samples of the team's next frame, fetched one frame ahead.  Nothing is done to a loaded value in the frame that
     // fetches it (not even float -> double): a use would make the wave wait for the load right there.  Branch-free:
@@ -281,7 +275,7 @@ __global__ void __launch_bounds__(kChromaWG) chroma_frames_kernel(ChromaArgs g) 
                 const long long sidx = g.frame_offset + (long long)frame * g.hop + 2 * n;
                 const double x0 = (sidx >= 0 && sidx < g.n_samples) ? (double)ps0[r] : 0.0;
                 const double x1 = (sidx + 1 >= 0 && sidx + 1 < g.n_samples) ? (double)ps1[r] : 0.0;
-                z[n] = make_double2(x0 * win_re[r], x1 * win_im[r]);
+                z[n] = make_double2(x0 * g.window[2 * n], x1 * g.window[2 * n + 1]);
             }
             fetch_frame(round + 1 < kChromaFR / 2 ? (long long)frame + 2
                                                   : (long long)frame0 + (long long)gridDim.x * kChromaFR + team);
