@@ -95,7 +95,8 @@ typedef struct rts_otw rts_otw;
  * LiveNoteV2.__init__ (livenote_v2.py:8-40) for B streams at once.  `ref_dev` ([N][F], dtype
  * `ref_dtype`) is held by reference like otw_eran.py:17 and must outlive the handle.  Instead of the
  * reference's dense (2N x N) cost/acc matrices the handle keeps two (c+1)-cell bands per stream.
- * F must be 12.  Supported band widths: 1 <= c <= 1012.  Above c = 500 only the default pipelined
+ * F must be 12.  Supported band widths: 1 <= c <= 2036 (LDS windows of 512 cells up to c = 500, 1024 up to 1012, 2048
+ * above).  Above c = 500 only the default pipelined
  * kernel exists (its helper waves read live frames from global memory instead of an LDS ring), so the
  * dense mirror (rts_otw_enable_dense / rts_otw_replay_dense) and RTS_OTW_SPEC=0 return
  * RTS_ERR_UNSUPPORTED with a message there, and live buffers must be 16-byte aligned. */

@@ -299,7 +299,7 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
                                             long long *rounds_acc = nullptr, bool prev0_xin = false, double alt_xin = 0.0,
                                             int *alt_ok = nullptr) {
     constexpr int L = W / 64;
-    constexpr int LOG_L = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
+    constexpr int LOG_L = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : (L == 16) ? 4 : 5;
     const double inf = INFINITY;
     // cell (lane, m) sits at band position q + L*lane with q = k1 + m wave-uniform, i.e. at LDS slot
     // (q mod L)*65 + ((q / L + lane) mod 64); slot[m] addresses position k - 1 of cell m
@@ -328,6 +328,9 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
             RTS_CHAIN_LOAD(0) RTS_CHAIN_LOAD(1) RTS_CHAIN_LOAD(2) RTS_CHAIN_LOAD(3) RTS_CHAIN_LOAD(4) RTS_CHAIN_LOAD(5)
             RTS_CHAIN_LOAD(6) RTS_CHAIN_LOAD(7) RTS_CHAIN_LOAD(8) RTS_CHAIN_LOAD(9) RTS_CHAIN_LOAD(10) RTS_CHAIN_LOAD(11)
             RTS_CHAIN_LOAD(12) RTS_CHAIN_LOAD(13) RTS_CHAIN_LOAD(14) RTS_CHAIN_LOAD(15)
+            RTS_CHAIN_LOAD(16) RTS_CHAIN_LOAD(17) RTS_CHAIN_LOAD(18) RTS_CHAIN_LOAD(19) RTS_CHAIN_LOAD(20) RTS_CHAIN_LOAD(21)
+            RTS_CHAIN_LOAD(22) RTS_CHAIN_LOAD(23) RTS_CHAIN_LOAD(24) RTS_CHAIN_LOAD(25) RTS_CHAIN_LOAD(26) RTS_CHAIN_LOAD(27)
+            RTS_CHAIN_LOAD(28) RTS_CHAIN_LOAD(29) RTS_CHAIN_LOAD(30) RTS_CHAIN_LOAD(31)
 #undef RTS_CHAIN_LOAD
         }
         chain_wait<L>(prevb, D);
@@ -397,7 +400,10 @@ __device__ __forceinline__ void strip_chain(const double *__restrict__ Dv, const
             RTS_CHAIN_STORE(0) RTS_CHAIN_STORE(1) RTS_CHAIN_STORE(2) RTS_CHAIN_STORE(3) RTS_CHAIN_STORE(4)
             RTS_CHAIN_STORE(5) RTS_CHAIN_STORE(6) RTS_CHAIN_STORE(7) RTS_CHAIN_STORE(8) RTS_CHAIN_STORE(9)
             RTS_CHAIN_STORE(10) RTS_CHAIN_STORE(11) RTS_CHAIN_STORE(12) RTS_CHAIN_STORE(13) RTS_CHAIN_STORE(14)
-            RTS_CHAIN_STORE(15)
+            RTS_CHAIN_STORE(15) RTS_CHAIN_STORE(16) RTS_CHAIN_STORE(17) RTS_CHAIN_STORE(18) RTS_CHAIN_STORE(19)
+            RTS_CHAIN_STORE(20) RTS_CHAIN_STORE(21) RTS_CHAIN_STORE(22) RTS_CHAIN_STORE(23) RTS_CHAIN_STORE(24)
+            RTS_CHAIN_STORE(25) RTS_CHAIN_STORE(26) RTS_CHAIN_STORE(27) RTS_CHAIN_STORE(28) RTS_CHAIN_STORE(29)
+            RTS_CHAIN_STORE(30) RTS_CHAIN_STORE(31)
 #undef RTS_CHAIN_STORE
         }
     } else {
@@ -2085,6 +2091,7 @@ static int launch(rts_otw *h, const OtwArgs &args, hipStream_t s) {
         case 256: return launch_w<256>(h, args, h->B, h->waves, s);
         case 512: return launch_w<512>(h, args, h->B, h->waves, s);
         case 1024: return launch_w<1024>(h, args, h->B, h->waves, s);  // c up to 1012: one workgroup per CU
+        case 2048: return launch_w<2048>(h, args, h->B, h->waves, s);  // c up to 2036: 32 cells per lane in the chains
     }
     return set_error(RTS_ERR_UNSUPPORTED, "no kernel for window %d", h->W);
 }
@@ -2126,8 +2133,8 @@ int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int 
     if (N < 1 || B < 1) return set_error(RTS_ERR_INVALID, "N and B must be >= 1 (got N=%d B=%d)", N, B);
     if (ref_dtype != RTS_F32 && ref_dtype != RTS_F64) return set_error(RTS_ERR_INVALID, "bad ref_dtype %d", ref_dtype);
     if (c < 1) return set_error(RTS_ERR_INVALID, "c must be >= 1 (got %d)", c);
-    if (c > 1012)
-        return set_error(RTS_ERR_UNSUPPORTED, "band width c=%d exceeds the 1012 cells the LDS-resident kernel holds", c);
+    if (c > 2036)
+        return set_error(RTS_ERR_UNSUPPORTED, "band width c=%d exceeds the 2036 cells the LDS-resident kernel holds", c);
     if (max_run_count < 1) return set_error(RTS_ERR_INVALID, "max_run_count must be >= 1");
     if (variant < RTS_VARIANT_OTW || variant > RTS_VARIANT_LIVENOTE_V2)
         return set_error(RTS_ERR_INVALID, "bad variant %d", variant);

@@ -21,7 +21,7 @@ its small outputs are committed.  What it does:
     int operands, Python 2 floor division -- to ``//``, and runs it on the two chopin WAVs:
     stft_golden.npz holds a handful of STFT columns and the sha256 of the whole complex matrix.
 
-Usage:  python tests/golden/make_golden.py      (takes ~1-2 minutes; reference is pure Python)
+Usage:  python tests/golden/make_golden.py      (takes ~5 minutes; reference is pure Python)
 """
 import contextlib
 import hashlib
@@ -219,6 +219,13 @@ def main():
     out["H/ref"], out["H/live"] = refH.astype(np.float32), liveH.astype(np.float32)
     add_case("H_otw_c800_insert", "otw", refH, liveH, 800, 3, "insert")
     add_case("H_livenote_v2_c1000_insert", "livenote_v2", refH, liveH, 1000, 3, "insert")
+
+    # ---- I: bands wider than 1012 cells (the 2048-cell window of the kernel; round 3) -------------------------
+    refI = synth.synth_ref(2300, seed=91)
+    liveI = synth.synth_live(refI, seed=92)
+    out["I/ref"], out["I/live"] = refI.astype(np.float32), liveI.astype(np.float32)
+    add_case("I_otw_c1500_insert", "otw", refI, liveI, 1500, 3, "insert")
+    add_case("I_livenote_v2_c2000_set_live", "livenote_v2", refI, liveI, 2000, 3, "set_live")
 
     # ---- chopin pair (real audio; chroma from the numpy oracle -- chroma.py needs librosa) ---
     wav_r, _ = chroma_oracle.load_wav_mono(os.path.join(REF, "Songs/chopin/chopin_rubinstein_20b.wav"))

@@ -24,9 +24,9 @@ def run(n_trials=120, seed=7, verbose=True):
     t0 = time.time()
     checked = 0
     for trial in range(n_trials):
-        c = int(rs.choice([53, 60, 64, 100, 116, 117, 130, 200, 244, 245, 300, 400, 500, 500, 501, 640, 1012]))
+        c = int(rs.choice([53, 60, 64, 100, 116, 117, 130, 200, 244, 245, 300, 400, 500, 500, 501, 640, 1012, 1013, 1500, 2036]))
         n_ref = int(rs.choice([c // 2 + 3, c + 1, c + 40, 2 * c, 3 * c]))
-        n_ref = min(n_ref, 1400)
+        n_ref = min(n_ref, 1400 if c <= 1012 else 2600)
         mrc = int(rs.choice([1, 2, 3, 5]))
         variant = str(rs.choice(["otw", "otw", "livenote", "livenote_v2"]))
         euclid = bool(variant == "livenote_v2" and rs.rand() < 0.4)

@@ -271,7 +271,7 @@ def test_argument_errors(gpu):
     nat, ob, synth = gpu["nat"], gpu["ob"], gpu["synth"]
     ref = synth.synth_ref(50, seed=1)
     with pytest.raises(nat.RtsyncError):
-        ob.BatchedOTW(ref, 1013, 3)   # band too wide for the LDS-resident kernel
+        ob.BatchedOTW(ref, 2037, 3)   # band too wide for the LDS-resident kernel
     with pytest.raises(nat.RtsyncError):
         ob.BatchedOTW(ref, 0, 3)
     with pytest.raises(nat.RtsyncError):
@@ -352,7 +352,7 @@ def test_soak_medium_and_wide_bands(gpu):
 
 
 def test_bands_wider_than_500_cells(gpu):
-    """500 < c <= 1012 run on the 1024-cell window: every variant against the
+    """500 < c <= 1012 run on the 1024-cell window, 1012 < c <= 2036 on the 2048-cell one: every variant against the
     dense oracle -- path, end state, both live bands -- plus the refusals the header documents.  (The reference-made
     goldens H_otw_c800 / H_livenote_v2_c1000 are covered by test_golden_cases.)"""
     import oracle
@@ -362,7 +362,8 @@ def test_bands_wider_than_500_cells(gpu):
     checked = 0
     for c, n_ref, variant, mode in ((501, 700, "otw", "insert"), (640, 1500, "livenote", "set_live"),
                                     (900, 1000, "livenote_v2", "insert"), (1012, 1600, "otw", "insert"),
-                                    (1012, 1100, "otw", "set_live")):
+                                    (1012, 1100, "otw", "set_live"), (1013, 1500, "otw", "insert"),
+                                    (1700, 2100, "livenote", "insert"), (2036, 2300, "livenote_v2", "set_live")):
         ref, lives = synth.synth_batch(n_ref, 3, seed=700 + c)
         lives[1] = lives[1][:, : max(5, lives[1].shape[1] // 2)]
         eng = ob.BatchedOTW(ref, c, 3, batch=3, variant=variant, dtype=torch.float32)
@@ -383,7 +384,7 @@ def test_bands_wider_than_500_cells(gpu):
             assert np.array_equal(rb, orb, equal_nan=True) and np.array_equal(cb, ocb, equal_nan=True), tag
             checked += 1
         eng.close()
-    assert checked == 15
+    assert checked == 24
     # float64 features and the per-call ingestion paths take the same window (no live ring in LDS: its helper waves
     # read live frames from global memory), so the drop-in classes work at these widths too
     ref, lives = synth.synth_batch(900, 2, seed=5)
@@ -416,4 +417,4 @@ def test_bands_wider_than_500_cells(gpu):
     with pytest.raises(nat.RtsyncError, match="dense"):      # ... and so does the C-ABI
         drop._eng.replay_dense()
     with pytest.raises(nat.RtsyncError):
-        ob.BatchedOTW(ref, 1013, 3, batch=1, dtype=torch.float32)
+        ob.BatchedOTW(ref, 2037, 3, batch=1, dtype=torch.float32)
