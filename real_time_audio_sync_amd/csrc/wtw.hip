@@ -733,8 +733,12 @@ __global__ void wtw_precheck_kernel(int32_t *state, int B, int M, int N) {
 // Append n_new[b] columns from cols [B][n_max][F] to the live history; columns beyond the 2M capacity
 // are dropped (the reference would raise IndexError at that column) and reported as status
 // LIVE_OVERFLOW by the advance kernel once it has walked the columns that did fit.
-__global__ void wtw_append_kernel(double *live, int32_t *appended, int32_t *state, const void *cols, int cols_f64,
-                                  const int32_t *n_new, int n_uniform, int n_max, int B, int N) {
+// grid (B, slices): a push of a whole recording is 200 KB per stream, so several workgroups share a stream's copy.  Every
+// slice reads the old count from `appended`; slice 0 writes the new one to `appended_next`, and the host swaps the two
+// arrays after the launch (the kernels that follow read the new one).
+constexpr int kWtwAppendSlices = 8;
+__global__ void wtw_append_kernel(double *live, int32_t *appended, int32_t *appended_next, int32_t *state, const void *cols,
+                                  int cols_f64, const int32_t *n_new, int n_uniform, int n_max, int B, int N) {
     const int b = blockIdx.x;
     if (b >= B) return;
     int nn = n_new ? n_new[b] : n_uniform;
@@ -742,18 +746,20 @@ __global__ void wtw_append_kernel(double *live, int32_t *appended, int32_t *stat
     const int base_raw = appended[b];
     const int base = base_raw < N ? base_raw : N;
     const int running = state[(size_t)b * 8 + 3] == RTS_RUNNING;
-    __syncthreads();
-    if (!running) return;  // sticky stop: later columns are ignored
     int take = nn;
     if (base + take > N) take = N - base > 0 ? N - base : 0;
-    for (int idx = threadIdx.x; idx < take * kWF; idx += blockDim.x) {
+    if (blockIdx.y == 0 && threadIdx.x == 0)
+        appended_next[b] = (!running || nn <= 0) ? base_raw : ((take < nn) ? N + 1 : base + take);  // N+1: a column was dropped
+    if (!running) return;  // sticky stop: later columns are ignored
+    const int total = take * kWF;
+    const int per = (total + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * per, hi = (lo + per < total) ? lo + per : total;
+    for (int idx = lo + threadIdx.x; idx < hi; idx += blockDim.x) {
         const size_t src = ((size_t)b * n_max) * kWF + idx;
         const double v = cols_f64 ? reinterpret_cast<const double *>(cols)[src]
                                   : (double)reinterpret_cast<const float *>(cols)[src];
         live[((size_t)b * N + base) * kWF + idx] = v;
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && nn > 0) appended[b] = (take < nn) ? N + 1 : base + take;  // N+1: a column was dropped
 }
 
 }  // namespace rts
@@ -762,7 +768,7 @@ struct rts_wtw {
     const double *ref;
     int M, N, B, W, hopf, path_cap;
     double *live;
-    int32_t *appended, *state, *path;
+    int32_t *appended, *appended_next, *state, *path;
     int8_t *bwork;
     double *dlast;
     int32_t *ws_sub, *ws_scr, *ctl, *err, *ticket, *entb, *cross, *lens;
@@ -863,6 +869,7 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     hipError_t e;
     if ((e = hipMalloc((void **)&h->live, sizeof(double) * kWF * (size_t)h->N * B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->appended, sizeof(int32_t) * (size_t)B)) != hipSuccess ||
+        (e = hipMalloc((void **)&h->appended_next, sizeof(int32_t) * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->state, sizeof(int32_t) * 8 * (size_t)B)) != hipSuccess ||
         (e = hipMalloc((void **)&h->path, sizeof(int32_t) * 2 * (size_t)h->path_cap * B)) != hipSuccess ||
         (!big && !win && W > kWtwLdsB && (e = hipMalloc((void **)&h->bwork, (size_t)B * W * W)) != hipSuccess) ||
@@ -918,6 +925,7 @@ int rts_wtw_destroy(rts_wtw *h) {
     if (!h) return RTS_OK;
     if (h->live) (void)hipFree(h->live);
     if (h->appended) (void)hipFree(h->appended);
+    if (h->appended_next) (void)hipFree(h->appended_next);
     if (h->state) (void)hipFree(h->state);
     if (h->path) (void)hipFree(h->path);
     if (h->bwork) (void)hipFree(h->bwork);
@@ -968,8 +976,13 @@ int rts_wtw_push(rts_wtw *h, const void *cols_dev, int cols_dtype, int n_max, co
         RTS_HIP(hipGetLastError());
     }
     if (n_max == 0) return RTS_OK;
-    hipLaunchKernelGGL(wtw_append_kernel, dim3(h->B), dim3(256), 0, s, h->live, h->appended, h->state, cols_dev,
-                       cols_dtype == RTS_F64, n_new_dev, n_max, n_max, h->B, h->N);
+    hipLaunchKernelGGL(wtw_append_kernel, dim3(h->B, n_max >= 64 ? kWtwAppendSlices : 1), dim3(256), 0, s, h->live, h->appended,
+                       h->appended_next, h->state, cols_dev, cols_dtype == RTS_F64, n_new_dev, n_max, n_max, h->B, h->N);
+    {
+        int32_t *t = h->appended;
+        h->appended = h->appended_next;
+        h->appended_next = t;
+    }
     RTS_HIP(hipGetLastError());
     WtwArgs g;
     g.ref = h->ref;

@@ -39,7 +39,7 @@ def test_error_reporting_without_gpu(nat):
     assert rc == -1 and b"ref_dev" in nat.lib.rts_last_error()
     rc = nat.lib.rts_otw_create(ctypes.c_void_p(16), nat.F32, 13, 10, 1, 5, 3, 0, 0, ctypes.byref(h))
     assert rc == -2 and b"12" in nat.lib.rts_last_error()
-    rc = nat.lib.rts_otw_create(ctypes.c_void_p(16), nat.F32, 12, 10, 1, 1013, 3, 0, 0, ctypes.byref(h))
+    rc = nat.lib.rts_otw_create(ctypes.c_void_p(16), nat.F32, 12, 10, 1, 2037, 3, 0, 0, ctypes.byref(h))
     assert rc == -2
     with pytest.raises(nat.RtsyncError):
         nat.check(nat.lib.rts_otw_set_waves(None, 4))
