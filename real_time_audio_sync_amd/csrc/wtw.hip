@@ -263,21 +263,28 @@ __global__ void __launch_bounds__(256) wtw_advance_kernel(WtwArgs g) {
 // ---- windows of at most kWinMaxW frames: every window of a push in ONE launch, one workgroup per stream -------------
 //
 // wtw_live.py runs W = 100 / hop = 50, tests.py:174 W = 20 / hop = 10: thousands of small windows per stream, each one
-// depending on the hand-over of the one before.  wtw_win_kernel<R, STAGE> keeps a stream's whole window loop on the device:
-//   1. all 256 threads: the full n x m cost matrix (1 - x.y / (|x| |y|), wtw.py:169, the reference's dot orders) into LDS
-//      -- lanes own columns (reference frame and norm in registers), waves share the rows (live frames broadcast from LDS);
-//   2. row 0 and column 0 of D are plain running sums (wtw.py:187-198): two lanes accumulate them, in the reference's
-//      order, into LDS.  The interior runs on R waves with one matrix row per lane and the lanes skewed in time (lane l of
-//      wave r owns row 1 + 64 r + l and handles column 1 + t - l at step t), so the three predecessors of a cell are
-//      registers: the lane's own previous value, the previous value of the lane above (DPP wave_shr:1; lane 0 receives
-//      row 0, or wave 0's bottom row, from LDS) and what that move delivered one step earlier.  Same float64 operations and
-//      candidate order as wtw.py:201-215 (sdp::WtwPolicy::cell), so D and the path are bit-identical.  With R = 2
-//      (65 < W <= 128) wave 1 runs 5 blocks of 16 steps behind wave 0; one workgroup barrier per 16 steps.
-//      Step codes: 2 bits per cell, 16 steps of a lane per dword.
-//   3. wave 0 walks the path back (find_path, wtw.py:219-240): the position lives in SGPRs, every lane holds the code
-//      word of its row for the current 16 steps, the code is one v_readlane away;
-//   4. all threads: hand-over (wtw.py:107-128) and the column bookkeeping up to the next window in closed form
-//      (the same rules as wtw_ctl_body below).
+// depending on the hand-over of the one before.  wtw_win_kernel<R, STAGE> keeps a stream's whole window loop on the device.
+// Per window k, between workgroup barriers:
+//   A. waves 1.. : the n x m cost matrix (1 - x.y / (|x| |y|), wtw.py:169, the reference's dot orders) into LDS -- lanes
+//      own columns (reference frame and norm in registers), the waves share the rows (each stages its own rows' live
+//      frames and their norms in a wave-private slice of LDS: no barrier inside the phase);
+//      wave 0, at the same time: find_path + hand-over of window k - 1 (below).
+//   B. row 0 and column 0 of D are running sums (wtw.py:187-198): two lanes accumulate them in the reference's order.
+//   C. the interior on R waves, one matrix row per lane, lanes skewed in time (lane l of wave r owns row 1 + 64 r + l and
+//      handles column 1 + t - l at step t): the three predecessors of a cell are registers -- the lane's own previous
+//      value, the previous value of the lane above (DPP wave_shr:1; lane 0 receives row 0, or wave 0's bottom row, from
+//      LDS) and what that move delivered one step earlier.  Same float64 operations and candidate order as
+//      wtw.py:201-215 (sdp::WtwPolicy::cell), so D and the path are bit-identical.  The block's 16 costs are fetched
+//      into registers before its 16 dependent steps.  With R = 2 (65 < W <= 128) wave 1 runs 5 blocks behind wave 0; one
+//      LDS barrier per 16 steps.  Step codes: 2 bits per cell, 16 steps of a lane per dword.
+//      Beside the values the lanes propagate, for every cell below row h = dtw_hop / hop, the column at which the cell's
+//      best path leaves row h (the same recurrence driven by the step codes; row h + 1 seeds it).  At the last cell that
+//      is the column r* of the last point the hand-over will append (wtw.py:113: l <= h), hence the next window's
+//      pointers (live_ptr + h, ref_ptr + r*; wtw.py:118-124) are known the moment the DP ends -- without the path.
+//   wave 0 in phase A of the next iteration walks the path back from (h, r*) -- only the part that is handed over; from
+//      (n-1, m-1) when the window is no taller than the hop -- with the position in SGPRs and the row's code word one
+//      v_readlane away (find_path, wtw.py:219-240), and appends it (wtw.py:107-117).
+// The column bookkeeping up to the next window is in closed form (the same rules as wtw_ctl_body below).
 constexpr int kWinMaxW = 128;   // what the kernel can do (RTS_WTW_WIN=1 forces it up to here)
 constexpr int kWinAutoW = 128;  // what it is chosen for by default
 constexpr int kWinKW = 12;       // code words per lane: 64 + 127 - 1 steps at most
@@ -287,13 +294,14 @@ constexpr int kWinPadBack = 208;  // (and ignore) whatever their row pointer + s
 __host__ __device__ inline int win_ldc(int W) { return (W | 1) + 1; }  // even > W: lanes a row apart hit different LDS banks
 __host__ __device__ inline size_t win_lds_bytes(int W) {
     const size_t feat = sizeof(double) * ((size_t)W * kWF + (size_t)W);                    // xs, nx
-    const size_t walk = sizeof(uint32_t) * 2 * kWinKW * 64 + sizeof(double) * 3 * (size_t)W +  // codes; row 0, column 0, bottom row of wave 0
-                        sizeof(int32_t) * 4 * (size_t)W;                                   // sub-path
+    const size_t walk = sizeof(uint32_t) * 2 * kWinKW * 64 + sizeof(double) * (3 * (size_t)W + 32) +  // codes; row 0, column 0 (padded), bottom row of wave 0
+                        sizeof(int32_t) * (size_t)W + sizeof(int32_t) * 4 * (size_t)W;     // its crossing columns; sub-path
     return sizeof(double) * ((size_t)W * win_ldc(W) + kWinPadFront + kWinPadBack) + feat + walk + 128;
 }
 
 #ifdef RTS_WIN_STAMPS
-// diagnostic build only: cycles of wave 0 of stream 0 per phase (load+norms, costs, DP, walk, hand-over), windows
+// diagnostic build only, stream 0: [0] phase A as wave 0 sees it (walk + hand-over + wait for the cost waves), [1] running
+// sums, [2] DP, [3] wave 0's own walk + hand-over, [4] wave 1's own cost phase, [5] windows
 __device__ long long g_win_stamps[8];
 #define RTS_WIN_STAMP(slot)                                                       \
     do {                                                                          \
@@ -310,28 +318,33 @@ __device__ long long g_win_stamps[8];
 template <int R, bool STAGE>
 __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) {
     constexpr int NT = (R == 1) ? 256 : 512;  // two waves per SIMD for the wide windows: their cost phase is fp64-bound
+    constexpr int NCW = NT / 64 - 1;          // cost waves: 1 .. NCW (wave 0 walks the previous window's path meanwhile)
     extern __shared__ __align__(16) unsigned char wtw_smem[];
     const int W = g.W, ldc = win_ldc(W);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int32_t *sh = reinterpret_cast<int32_t *>(wtw_smem);                          // [32] control words
     double *C = reinterpret_cast<double *>(wtw_smem + 128) + kWinPadFront;        // [W][ldc]
-    double *xs = C + (size_t)W * ldc + kWinPadBack;                               // [W][F] live window
+    double *xs = C + (size_t)W * ldc + kWinPadBack;                               // [W][F] live window (row i staged by wave 1 + i % NCW)
     double *nx = xs + (size_t)W * kWF;                                            // [W]
     uint32_t *codes = reinterpret_cast<uint32_t *>(nx + W);                       // [2][kWinKW][64]
-    double *row0 = reinterpret_cast<double *>(codes + 2 * kWinKW * 64);           // [W] D[0][:]
-    double *col0 = row0 + W;                                                      // [W] D[:][0]
-    double *bot = col0 + W;                                                       // [W] D[64][:] (wave 0's last row)
-    int32_t *sub = reinterpret_cast<int32_t *>(bot + W);                          // [2W][2], reversed
+    double *row0 = reinterpret_cast<double *>(codes + 2 * kWinKW * 64);           // [W + 16] D[0][:]
+    double *col0 = row0 + W + 16;                                                 // [W + 16] D[:][0]
+    double *bot = col0 + W + 16;                                                  // [W] D[64][:] (wave 0's last row)
+    int32_t *botx = reinterpret_cast<int32_t *>(bot + W);                         // [W] ... and its crossing columns
+    int32_t *sub = botx + W;                                                      // [2W][2], reversed
 
     int32_t *st = g.state + (size_t)b * 8;
     const double *live = g.live + (size_t)b * g.N * kWF;
     int32_t *path = g.path + (size_t)b * g.path_cap * 2;
     const int appended_raw = g.appended[b];
     const int appended = appended_raw < g.N ? appended_raw : g.N;
-    // state in registers (uniform: every thread computes the same values)
+    // state in registers (uniform: every thread computes the same values; n_path is kept by wave 0 only)
     int chroma_ptr = st[0], live_ptr = st[1], ref_ptr = st[2], status = st[3], n_path = st[4], n_windows = st[5];
     long long cells = ((long long)(uint32_t)st[7] << 32) | (uint32_t)st[6];
+    // the window whose path wave 0 still has to walk: its pointers and where the walk starts
+    int have_prev = 0, plp = 0, prp = 0, pwi = 0, pwj = 0;
+    const int h = g.hopf;
 
     for (;;) {
         // ---- wtw.py:92-100 in closed form up to the next window (see wtw_ctl_body)
@@ -351,54 +364,138 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
                 chroma_ptr = appended;
             }
         }
-        if (!pending) break;
+        if (!pending && !have_prev) break;
         const int lp = live_ptr, rp = ref_ptr;
 #ifdef RTS_WIN_STAMPS
         long long stamp_t = (long long)__builtin_amdgcn_s_memtime();
 #endif
-        // ---- 1. cost matrix.  Lanes own columns (the reference frame and its norm stay in registers), waves share the
-        // rows (the live frame is a wave-uniform LDS read: a broadcast), consecutive lanes store consecutive words.
-        __syncthreads();  // the previous window's walk / hand-over is done with sub[] and the codes
-        for (int idx = tid; idx < n * kWF; idx += NT) xs[idx] = live[(size_t)lp * kWF + idx];
-        __syncthreads();
-        for (int i = tid; i < n; i += NT) {
-            double x[kWF];
+        // ---- A. wave 0: path + hand-over of the previous window; waves 1..: this window's cost matrix
+        if (wave == 0) {
+            if (have_prev) {
+#ifdef RTS_WIN_STAMPS
+                const long long w0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+                // find_path (wtw.py:219-240) from the last point that is handed over back to (0, 0); sub[] holds it reversed
+                int i = pwi, j = pwj, len = 1;
+                if (lane == 0) {
+                    sub[0] = i;
+                    sub[1] = j;
+                }
+                int cur = -1;
+                uint32_t cw = 0;
+                while (i > 0 && j > 0) {  // interior cells: the code of (i, j) is bit pair t & 15 of word t >> 4 of lane (i-1) & 63
+                    const int l = (i - 1) & 63;
+                    const int t = l + j - 1;
+                    const int key = ((i - 1) >> 6) * kWinKW + (t >> 4);
+                    if (key != cur) {  // uniform
+                        cw = codes[(size_t)key * 64 + lane];
+                        cur = key;
+                    }
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cw, l);
+                    const int code = (int)((w >> (2 * (t & 15))) & 3u);
+                    i -= (code != sdp::kLeft) ? 1 : 0;   // kUp, kDiag
+                    j -= (code != sdp::kUp) ? 1 : 0;     // kLeft, kDiag
+                    if (lane == 0) {
+                        sub[2 * len] = i;
+                        sub[2 * len + 1] = j;
+                    }
+                    len++;
+                }
+                // on row 0 the path runs left, on column 0 up (wtw.py:187-198): the rest is a straight line to (0, 0)
+                const int rest = i + j;  // one of them is 0
+                for (int q = lane; q < rest; q += 64) {
+                    sub[2 * (len + q)] = i > 0 ? i - 1 - q : 0;
+                    sub[2 * (len + q) + 1] = j > 0 ? j - 1 - q : 0;
+                }
+                len += rest;
+                // hand-over (wtw.py:107-117): every walked point has l <= dtw_hop / hop; forwards
+                for (int f = lane; f < len; f += 64) {
+                    if (n_path + f < g.path_cap) {
+                        path[2 * (size_t)(n_path + f)] = sub[2 * (len - 1 - f)] + plp;
+                        path[2 * (size_t)(n_path + f) + 1] = sub[2 * (len - 1 - f) + 1] + prp;
+                    }
+                }
+                n_path += len;
+#ifdef RTS_WIN_STAMPS
+                if (b == 0 && lane == 0) g_win_stamps[3] += (long long)__builtin_amdgcn_s_memtime() - w0_;
+#endif
+            }
+        } else if (pending) {
+#ifdef RTS_WIN_STAMPS
+            const long long c0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+            const int cwv = wave - 1;
+            // my columns' reference frames first (their latency hides behind the staging of the rows)
+            double y0[kWF], y1[kWF];
+            sdp::load_frame(g.ref, 1, (long long)rp + (lane < m ? lane : m - 1), y0);
+            if (m > 64) sdp::load_frame(g.ref, 1, (long long)rp + (64 + lane < m ? 64 + lane : m - 1), y1);
+            // my rows (cwv, cwv + NCW, ...) into my slice of xs / nx: wave-private, no barrier
+            const int nrows = (n - cwv + NCW - 1) / NCW;
+            for (int q = lane; q < nrows * kWF; q += 64) {
+                const int row = cwv + NCW * (q / kWF);
+                xs[row * kWF + q % kWF] = live[(size_t)(lp + row) * kWF + q % kWF];
+            }
+            for (int q = lane; q < nrows; q += 64) {
+                const int row = cwv + NCW * q;
+                double x[kWF];
 #pragma unroll
-            for (int f = 0; f < kWF; f++) x[f] = xs[i * kWF + f];
-            nx[i] = sdp::WtwPolicy::norm(x);
+                for (int f = 0; f < kWF; f++) x[f] = xs[row * kWF + f];
+                nx[row] = sdp::WtwPolicy::norm(x);
+            }
+            const double ny0 = sdp::WtwPolicy::norm(y0);
+            const double ny1 = (m > 64) ? sdp::WtwPolicy::norm(y1) : 1.0;
+            for (int i = cwv; i < n; i += NCW) {
+                double x[kWF];
+#pragma unroll
+                for (int f = 0; f < kWF; f++) x[f] = xs[i * kWF + f];  // wave-uniform: a broadcast
+                const double nxi = nx[i];
+                const double c0 = sdp::WtwPolicy::cost(x, nxi, y0, ny0);  // wtw.py:169
+                if (lane < m) C[(size_t)i * ldc + lane] = c0;
+                if (m > 64) {
+                    const double c1 = sdp::WtwPolicy::cost(x, nxi, y1, ny1);
+                    if (64 + lane < m) C[(size_t)i * ldc + 64 + lane] = c1;
+                }
+            }
+#ifdef RTS_WIN_STAMPS
+            if (b == 0 && tid == 64) g_win_stamps[4] += (long long)__builtin_amdgcn_s_memtime() - c0_;
+#endif
         }
         __syncthreads();
         RTS_WIN_STAMP(0);
-        for (int j0 = 0; j0 < m; j0 += 64) {
-            const int j = j0 + lane;
-            double y[kWF];
-            sdp::load_frame(g.ref, 1, (long long)rp + (j < m ? j : m - 1), y);
-            const double nyj = sdp::WtwPolicy::norm(y);
-            for (int i = wave; i < n; i += NT / 64) {
-                double x[kWF];
-#pragma unroll
-                for (int f = 0; f < kWF; f++) x[f] = xs[i * kWF + f];
-                const double c = sdp::WtwPolicy::cost(x, nx[i], y, nyj);  // wtw.py:169
-                if (j < m) C[(size_t)i * ldc + j] = c;
-            }
+        if (!pending) {  // that was the last window's path
+            have_prev = 0;
+            continue;
         }
-        __syncthreads();
-        // row 0 (lane 0) and column 0 (lane 1) of D: running sums in the reference's order (wtw.py:183-198), the costs
-        // fetched 16 at a time so that the LDS latency is paid once per 16 dependent adds
+        // ---- B. row 0 (lane 0) and column 0 (lane 1) of D: running sums in the reference's order (wtw.py:183-198).  16
+        // costs per LDS round trip, then 16 dependent adds; the stores run up to 15 elements past the end (the arrays
+        // are padded for it), so nothing in the loop depends on the element count
         if (wave == 0 && lane < 2) {
             const int cnt = lane == 0 ? m : n;
+            const double *src = C;
             const int stride = lane == 0 ? 1 : ldc;
             double *out = lane == 0 ? row0 : col0;
             double acc = 0.0;
             for (int q0 = 0; q0 < cnt; q0 += 16) {
                 double v[16];
 #pragma unroll
-                for (int q = 0; q < 16; q++) v[q] = C[(size_t)((q0 + q) < cnt ? (q0 + q) : 0) * stride];
+                for (int q = 0; q < 16; q++) v[q] = src[q * stride];  // (past the end: the padding behind C)
+                src += 16 * stride;
+                if (q0 == 0) {
+                    acc = v[0];
+                    out[0] = acc;
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    acc = (q0 + q == 0) ? v[q] : acc + v[q];
-                    if (q0 + q < cnt) out[q0 + q] = acc;
+                    for (int q = 1; q < 16; q++) {
+                        acc = acc + v[q];
+                        out[q] = acc;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        acc = acc + v[q];
+                        out[q] = acc;
+                    }
                 }
+                out += 16;
             }
         }
         __syncthreads();
@@ -408,7 +505,8 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
             for (int q = tid; q < n; q += NT) dl[(size_t)q * W] = col0[q];
         }
         RTS_WIN_STAMP(1);
-        // ---- 2. interior DP: lane l of wave r owns row 1 + 64 r + l, column 1 + t - l at local step t
+        // ---- C. interior DP: lane l of wave r owns row 1 + 64 r + l, column 1 + t - l at local step t
+        const bool has_cross = h + 1 <= n - 1;  // the path goes below row h: wtw.py:118-124's "change"
         {
             const int r = wave;
             const int nint = n - 1, mint = m - 1;                       // interior rows / columns
@@ -423,6 +521,9 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
             const int ic = i < n ? i : n - 1;
             // D[i][0] and D[i-1][0]: what the first interior step of this lane sees as `left` and `diag`
             double dlast_v = col0[ic], du_prev = col0[ic - 1 >= 0 ? ic - 1 : 0];
+            // crossing columns: column 0 is left through (h, 0)
+            int xl = 0, xu_prev = 0;
+            const bool is_h1 = (i == h + 1);
             const double *upin = (r == 0) ? row0 : bot;                  // the row above this wave's lane 0
             double *dout = STAGE ? g.dlast + ((size_t)b * W + ic) * W : nullptr;
             const double *crow = C + (size_t)ic * ldc + 1 - lane;         // crow[t] = C[i][1 + t - lane]
@@ -433,101 +534,61 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
                 // the block's 16 costs and 16 values of the row above lane 0 first (independent of the recurrence: one
                 // LDS round trip per block instead of one per step)
                 double cbuf[16], ubuf[16];
+                int uxbuf[16];
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int t = 16 * kb + q;
                     cbuf[q] = crow[t];
                     ubuf[q] = upin[(t + 1 < m) ? t + 1 : 0];
+                    uxbuf[q] = (R > 1 && r > 0) ? botx[(t + 1 < m) ? t + 1 : 0] : 0;
                 }
                 uint32_t word = 0;
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int t = 16 * kb + q;  // (steps past T - 1 compute and store nothing anybody reads)
                     const unsigned jj = (unsigned)(t - lane);            // column - 1
-                    const bool valid = jj < (unsigned)mint && lane < rows;
+                    const bool incol = jj < (unsigned)mint;
+                    const bool valid = incol && lane < rows;
                     const double du = sdp::shr1(dlast_v, ubuf[q]);        // D[i-1][j]; lane 0: from LDS
+                    const int xu = sdp::shr1_i(xl, uxbuf[q]);
                     double dv;
                     int code;
                     sdp::WtwPolicy::cell(false, false, du, dlast_v, du_prev, cbuf[q], dv, code);  // wtw.py:201-215
+                    int xn = (code == sdp::kUp) ? xu : ((code == sdp::kDiag) ? xu_prev : xl);
+                    const int xh = (code == sdp::kUp) ? (int)jj + 1 : ((code == sdp::kDiag) ? (int)jj : xl);
+                    xn = is_h1 ? xh : xn;                                  // row h + 1: its predecessors in row h ARE the crossing
                     du_prev = du;                                          // D[i-1][j-1] of the next step
+                    xu_prev = xu;
                     word |= (uint32_t)code << (2 * q);                     // (codes of cells outside the matrix are never read)
-                    if (t >= lane) dlast_v = dv;                           // D[i][j-1] of the next step; untouched before the lane's first cell
+                    if (incol) {                                           // untouched before the lane's first and after its last cell
+                        dlast_v = dv;                                      // D[i][j-1] of the next step
+                        xl = xn;
+                    }
                     if (valid) {
-                        if (R > 1 && r == 0 && lane == 63) bot[jj + 1] = dv;
+                        if (R > 1 && r == 0 && lane == 63) {
+                            bot[jj + 1] = dv;
+                            botx[jj + 1] = xn;
+                        }
                         if (STAGE) dout[jj + 1] = dv;
                     }
                 }
                 codes[((size_t)r * kWinKW + kb) * 64 + lane] = word;
             }
+            if (r < R && lane < rows && i == n - 1) sh[2] = xl;  // the last cell's crossing column
         }
         __syncthreads();
         RTS_WIN_STAMP(2);
-        // ---- 3. find_path (wtw.py:219-240) by wave 0: sub[] holds the path reversed, sh[0] its length
-        if (wave == 0) {
-            int i = n - 1, j = m - 1, len = 1;
-            if (lane == 0) {
-                sub[0] = i;
-                sub[1] = j;
-            }
-            int cur = -1;
-            uint32_t cw = 0;
-            while (i > 0 && j > 0) {  // interior cells: the code of (i, j) is bit pair t & 15 of word t >> 4 of lane (i-1) & 63
-                const int l = (i - 1) & 63;
-                const int t = l + j - 1;
-                const int key = ((i - 1) >> 6) * kWinKW + (t >> 4);
-                if (key != cur) {  // uniform
-                    cw = codes[(size_t)key * 64 + lane];
-                    cur = key;
-                }
-                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cw, l);
-                const int code = (int)((w >> (2 * (t & 15))) & 3u);
-                i -= (code != sdp::kLeft) ? 1 : 0;   // kUp, kDiag
-                j -= (code != sdp::kUp) ? 1 : 0;     // kLeft, kDiag
-                if (lane == 0) {
-                    sub[2 * len] = i;
-                    sub[2 * len + 1] = j;
-                }
-                len++;
-            }
-            // on row 0 the path runs left, on column 0 up (wtw.py:187-198): the rest is a straight line to (0, 0)
-            const int rest = i + j;  // one of them is 0
-            for (int q = lane; q < rest; q += 64) {
-                sub[2 * (len + q)] = i > 0 ? i - 1 - q : 0;
-                sub[2 * (len + q) + 1] = j > 0 ? j - 1 - q : 0;
-            }
-            len += rest;
-            if (lane == 0) {
-                sh[0] = len;
-                sh[1] = 0;
-            }
-        }
-        __syncthreads();
-        RTS_WIN_STAMP(3);
-        // ---- 4. hand-over (wtw.py:107-128): l is non-decreasing along the path, so the points with l <= dtw_hop / hop
-        // are a prefix of it
-        const int len = sh[0];
-        int local = 0;
-        for (int f = tid; f < len; f += NT) local += (sub[2 * (len - 1 - f)] <= g.hopf) ? 1 : 0;
-        if (local) atomicAdd(&sh[1], local);
-        __syncthreads();
-        const int cnt = sh[1];
-        for (int f = tid; f < cnt; f += NT) {
-            if (n_path + f < g.path_cap) {
-                path[2 * (size_t)(n_path + f)] = sub[2 * (len - 1 - f)] + lp;
-                path[2 * (size_t)(n_path + f) + 1] = sub[2 * (len - 1 - f) + 1] + rp;
-            }
-        }
-        if (cnt < len && cnt >= 1) {  // "change": the path went past the hop (wtw.py:118-124)
-            live_ptr = lp + sub[2 * (len - cnt)];
-            ref_ptr = rp + sub[2 * (len - cnt) + 1];
-        } else {
-            live_ptr = lp + g.hopf;
-            ref_ptr = rp + g.hopf;
-        }
-        n_path += cnt;
+        // ---- the next window's pointers (wtw.py:118-128), and what wave 0 walks during the next phase A
+        const int xstar = (has_cross && m > 1) ? sh[2] : 0;  // (m == 1: the path is column 0)
+        plp = lp;
+        prp = rp;
+        pwi = has_cross ? h : n - 1;
+        pwj = has_cross ? xstar : m - 1;
+        have_prev = 1;
+        live_ptr = lp + h;
+        ref_ptr = rp + (has_cross ? xstar : h);
         n_windows += 1;
         cells += (long long)n * m;
-        RTS_WIN_STAMP(4);
 #ifdef RTS_WIN_STAMPS
         if (b == 0 && tid == 0) g_win_stamps[5] += 1;
 #endif

@@ -84,7 +84,7 @@ def main():
     st = eng.states()
     frames = int(st[:, 0].sum())
     cells = int(sum((int(np.uint32(s[7])) << 32) | int(np.uint32(s[6])) for s in st))
-    out.append(dict(kernel="wtw_advance_kernel", streams=64, W=100, hop=50, frames=frames, windows=int(st[:, 5].sum()),
+    out.append(dict(kernel="wtw_win_kernel (every window of the push in one launch)", streams=64, W=100, hop=50, frames=frames, windows=int(st[:, 5].sum()),
                     seconds=t, frames_per_s=frames / t, cells_per_s=cells / t))
     # one long-form stream, W = 10 000 (configs[4] shape)
     ref5 = synth.synth_ref(19380, seed=500)
@@ -192,11 +192,11 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     frames = int(sess.otw.states()[:, 8].sum())
-    out.append(dict(kernel="LiveSession.feed (H2D copy + chroma_frames_kernel + otw_advance_kernel + host bookkeeping)",
+    out.append(dict(kernel="LiveSession.feed(list of 64 arrays) via rts_live_* (one H2D + append + chroma + OTW push + compact per feed; tools/bench_live.py has the other modes)",
                     streams=64, audio_seconds_per_stream=secs - 3, wall_seconds=dt,
                     realtime_factor=(secs - 3) / dt, frames_per_s=64 * (secs - 3) * 22050 / 2048 / dt,
                     frames_total=frames,
-                    note="random audio (worst case for the tracker); per feed: 64 small H2D copies + 2 launches + a 4 KB state read-back"))
+                    note="random audio (worst case for the tracker); per feed: 64 numpy copies into the pinned staging slot, nothing read back"))
     for o in out:
         print(json.dumps(o))
 

@@ -57,8 +57,8 @@ def main():
                 buf = (ctypes.c_longlong * 8)()
                 eng_lib().rts_wtw_read_win_stamps(buf)
                 wn = max(buf[5], 1)
-                print(json.dumps(dict(W=W, stamps_cycles_per_window=dict(load_norms=buf[0] / wn, costs=buf[1] / wn, dp=buf[2] / wn,
-                                                                          walk=buf[3] / wn, handover=buf[4] / wn), windows_stream0=int(buf[5]))), flush=True)
+                print(json.dumps(dict(W=W, stamps_cycles_per_window=dict(phase_a_wave0=buf[0] / wn, running_sums=buf[1] / wn, dp=buf[2] / wn,
+                                                                          walk_handover_wave0=buf[3] / wn, costs_wave1=buf[4] / wn), windows_stream0=int(buf[5]))), flush=True)
             eng.close()
         assert all(np.array_equal(a, b) for a, b in zip(paths["default"], paths["RTS_WTW_WIN=0"])), W
 
