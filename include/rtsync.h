@@ -96,10 +96,10 @@ typedef struct rts_otw rts_otw;
  * `ref_dtype`) is held by reference like otw_eran.py:17 and must outlive the handle.  Instead of the
  * reference's dense (2N x N) cost/acc matrices the handle keeps two (c+1)-cell bands per stream.
  * F must be 12.  Supported band widths: 1 <= c <= 2036 (LDS windows of 512 cells up to c = 500, 1024 up to 1012, 2048
- * above).  Above c = 500 only the default pipelined
- * kernel exists (its helper waves read live frames from global memory instead of an LDS ring), so the
- * dense mirror (rts_otw_enable_dense / rts_otw_replay_dense) and RTS_OTW_SPEC=0 return
- * RTS_ERR_UNSUPPORTED with a message there, and live buffers must be 16-byte aligned. */
+ * above).  Above c = 500 no frame ring fits in LDS beside the bands: the default pipelined kernel and the dense mirror
+ * (rts_otw_set_dense / rts_otw_replay_dense: the plain 8-wave kernel) read every frame from global memory, live buffers
+ * must be 16-byte aligned, and RTS_OTW_SPEC=0 (the plain kernel without the dense mirror: an A/B knob) returns
+ * RTS_ERR_UNSUPPORTED with a message. */
 int rts_otw_create(const void *ref_dev, int ref_dtype, int F, int N, int B, int c, int max_run_count,
                    int variant, int cost_kind, rts_otw **out);
 int rts_otw_destroy(rts_otw *h);
@@ -149,8 +149,8 @@ int rts_otw_set_dense(rts_otw *h, double *acc_dev, double *cost_dev, void *strea
  * rts_otw_push are kept by the handle: pass live_dev = NULL (live_dtype, T_max, live_len_dev ignored).  Frames of an
  * rts_otw_run are the caller's memory and the library keeps no pointer to them: pass that call's live_dev, live_dtype,
  * T_max and live_len_dev again (dtype and T_max are checked against the run being replayed).  The handle's own state is
- * not touched, so the streams keep running on the pipelined kernel.  Band widths up to 500 (RTS_ERR_UNSUPPORTED above:
- * only the live bands exist there).  Synchronises `stream`.  What the drop-in classes' .acc_cost / .cost
+ * not touched, so the streams keep running on the pipelined kernel.  Every supported band width.  Synchronises `stream`.
+ * What the drop-in classes' .acc_cost / .cost
  * (otw_eran.py:23,27) are made of. */
 int rts_otw_replay_dense(rts_otw *h, const void *live_dev, int live_dtype, int T_max, const int32_t *live_len_dev,
                          double *acc_dev, double *cost_dev, void *stream);

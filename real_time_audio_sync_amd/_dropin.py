@@ -100,10 +100,6 @@ class OtwDropIn(object):
                 "the dense (2N x N) %s of the reference is not kept for a reference this long (it would need "
                 "%.1f GiB); use .bands() for the two live bands the algorithm actually reads"
                 % (which, 2 * (2 * self._ref_host.shape[1]) * self._ref_host.shape[1] * 8 / 2.0 ** 30))
-        if self._eng.c > 500:
-            raise NotImplementedError(
-                "the dense (2N x N) %s of the reference is produced for band widths up to 500 (this instance: %d); "
-                "use .bands() for the two live bands the algorithm actually reads" % (which, self._eng.c))
         if getattr(self, "_dense_cache", (None,))[0] != self._eng._version:
             acc, cost = self._eng.replay_dense()
             self._dense_cache = (self._eng._version, acc[0].cpu().numpy(), cost[0].cpu().numpy())

@@ -559,6 +559,9 @@ __device__ __forceinline__ void otw_commit_ref(OtwLds<W, RT> &S, OtwCtl &k, cons
     otw_prefetch_ref(k, e);
 }
 
+__device__ __forceinline__ void otw_ref_frame(const OtwEnv &e, int q, double (&rf)[kF]);
+__device__ __forceinline__ void otw_live_frame(const OtwEnv &e, int r, double (&lf)[kF]);
+
 // Speculative costs for the step after the one that leaves the state at (t_now, j_now): row t_now+1
 // over columns [j_now-c+1, j_now] and column j_now+1 over rows [t_now-c+1, t_now+1] cover every
 // possible next step (Row, Both or Column).  hidx / hn: index and count of the threads sharing it.
@@ -574,6 +577,29 @@ __device__ __forceinline__ void otw_precompute(OtwLds<W, RT> &S, const OtwEnv &e
     const int r1 = (t_now - c + 1 > 0) ? t_now - c + 1 : 0;
     const int rtop = row_ok ? tn : t_now;
     const int ncol = col_ok ? rtop - r1 + 1 : 0;
+    if constexpr (!kHasLiveRing<RT>) {
+        // no rings (the dense mirror of a window of 1024 cells or more: the bands leave no room for them): every frame
+        // straight from global memory -- the reference is L2-resident, the live frames of a stream are 48 / 96 bytes each
+        if (nrow > 0) {
+            double lf[kF];
+            otw_live_frame(e, tn, lf);
+            for (int i = hidx; i < nrow; i += hn) {
+                double rf[kF];
+                otw_ref_frame(e, k1 + i, rf);
+                Drn[swz<W>(k1 + i)] = cell_cost(lf, rf, e.euclid);
+            }
+        }
+        if (ncol > 0) {
+            double rf[kF];
+            otw_ref_frame(e, jn1, rf);
+            for (int i = hidx; i < ncol; i += hn) {
+                double lf[kF];
+                otw_live_frame(e, r1 + i, lf);
+                Dcn[swz<W>(r1 + i)] = cell_cost(lf, rf, e.euclid);
+            }
+        }
+        return;
+    }
     if (nrow > 0) {
         double lf[kF];
 #pragma unroll
@@ -767,9 +793,11 @@ __device__ __forceinline__ OtwPlan otw_make_plan(OtwLds<W, RT> &S, OtwCtl &k, co
     }
     // keep the rings one frame ahead of what this step's cost pre-computation will read (the pipelined kernel
     // leaves the rings to its first helper wave)
-    if (!spec && !(flags & kPlanExit)) {
-        const int jn_p = k.j + ((flags & kPlanCol) ? 1 : 0);
-        otw_refill<W, RT>(S, k, e, pt + 1, jn_p + 1);
+    if constexpr (kHasLiveRing<RT>) {
+        if (!spec && !(flags & kPlanExit)) {
+            const int jn_p = k.j + ((flags & kPlanCol) ? 1 : 0);
+            otw_refill<W, RT>(S, k, e, pt + 1, jn_p + 1);
+        }
     }
     OtwPlan p;
     p.t = pt;
@@ -1299,7 +1327,9 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     OtwLds<W, RT> &S = *reinterpret_cast<OtwLds<W, RT> *>(smem_raw);
     using LdsT = OtwLds<W, RT>;
     constexpr bool kNoLiveRing = !kHasLiveRing<RT>;  // live frames read from global memory by the helpers
-    static_assert(SPEC || !kNoLiveRing, "only the pipelined kernel runs without a live ring");
+    // no reference ring either: the pipelined kernel always, the others when they run without a live ring (dense mirror
+    // of a window of 1024 cells or more) -- the struct is then allocated only up to `refw`
+    constexpr bool kRefRing = !SPEC && !kNoLiveRing;
     constexpr size_t kSpecOff = (offsetof(LdsT, refw) + 15) & ~(size_t)15;  // SPEC: no reference ring
     OtwSpecLds<W> &SP = *reinterpret_cast<OtwSpecLds<W> *>(smem_raw + kSpecOff);  // only touched when SPEC
 
@@ -1399,7 +1429,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
                 S.livew[f][fr & (W - 1)] = (typename RingElem<RT>::type)otw_load_feat(a.live, a.live_f64, e.live_base + (long long)fr * kF + f);
             }
         }
-        if (!SPEC) {
+        if constexpr (kRefRing) {
             for (int idx = tid; idx < (k.ref_hi - lo_r + 1) * kF; idx += NT) {
                 const int fr = lo_r + idx / kF, f = idx % kF;
                 S.refw[f][fr & (W - 1)] = (typename RingElem<RT>::type)otw_load_feat(a.ref, a.ref_f64, (long long)fr * kF + f);
@@ -1417,7 +1447,7 @@ __global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
     }
     if (wave == (SPEC ? HW0 : 0)) {  // the wave that will refill the rings starts its first prefetch
         if constexpr (!kNoLiveRing) otw_prefetch_live(k, e);
-        if (!SPEC) otw_prefetch_ref(k, e);
+        if constexpr (kRefRing) otw_prefetch_ref(k, e);
     }
     if (wave == 0) {
         if (k.first) {
@@ -2023,7 +2053,8 @@ static int ensure_lds_attr(rts_otw *h, const void *fn, size_t smem) {
 template <int W, int NW, bool DENSE, typename RT, bool SPEC>
 static int launch_advance_d(rts_otw *h, const OtwArgs &args, int B, hipStream_t s) {
     using LdsT = OtwLds<W, RT>;
-    const size_t smem = SPEC ? ((offsetof(LdsT, refw) + 15) & ~(size_t)15) + sizeof(OtwSpecLds<W>) : sizeof(LdsT);
+    const size_t smem = SPEC ? ((offsetof(LdsT, refw) + 15) & ~(size_t)15) + sizeof(OtwSpecLds<W>)
+                             : (kHasLiveRing<RT> ? sizeof(LdsT) : ((offsetof(LdsT, refw) + 15) & ~(size_t)15));
     const int rc = ensure_lds_attr(h, reinterpret_cast<const void *>(&otw_advance_kernel<W, NW, DENSE, RT, SPEC>), smem);
     if (rc != RTS_OK) return rc;
     hipLaunchKernelGGL((otw_advance_kernel<W, NW, DENSE, RT, SPEC>), dim3(B), dim3(64 * NW), smem, s, args);
@@ -2035,13 +2066,13 @@ static int launch_advance_d(rts_otw *h, const OtwArgs &args, int B, hipStream_t 
 template <int W, int NW>
 static int launch_advance(rts_otw *h, const OtwArgs &args, int B, hipStream_t s) {
     if constexpr (W >= 1024) {
-        // no ring fits beside a 1024-cell window's bands: only the pipelined kernel, reading live frames from global memory
+        // no ring fits beside a 1024-cell window's bands: every frame is read from global memory.  The dense mirror
+        // (otw_eran.py:23,27) runs the plain role-specialised kernel that way, in its 8-wave form whatever rts_otw_set_waves says
+        if (args.dense_acc) return launch_advance_d<W, 8, true, LiveFromGlobal, false>(h, args, B, s);
         if constexpr (NW >= 8) {
-            if (args.spec && !args.dense_acc) return launch_advance_d<W, NW, false, LiveFromGlobal, true>(h, args, B, s);
+            if (args.spec) return launch_advance_d<W, NW, false, LiveFromGlobal, true>(h, args, B, s);
         }
-        return set_error(RTS_ERR_UNSUPPORTED,
-                         "band widths above 500 (c=%d) run only on the pipelined 8-wave kernel, without the dense mirror",
-                         h->c);
+        return set_error(RTS_ERR_UNSUPPORTED, "band widths above 500 (c=%d) run only on the pipelined 8-wave kernel", h->c);
     }
     if (args.dense_acc) return launch_advance_d<W, NW, true, double, false>(h, args, B, s);
     // float32 rings only when both inputs are float32: every value then widens back exactly
@@ -2255,9 +2286,6 @@ int rts_otw_replay_dense(rts_otw *h, const void *live_dev, int live_dtype, int T
     } else if (live_dev) {
         return set_error(RTS_ERR_INVALID, "the handle's frames came through rts_otw_insert / rts_otw_push (or it is fresh): live_dev must be NULL");
     }
-    if (h->c > 500)
-        return set_error(RTS_ERR_UNSUPPORTED, "the dense (2N x N) matrices are produced for band widths up to 500 (c=%d): above that only the "
-                                              "two live bands exist (rts_otw_read_bands)", h->c);
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)h->B * h->live_cap * h->N;
     const double sentinel = (h->variant == RTS_VARIANT_OTW) ? 1e10 : (double)INFINITY;

@@ -407,14 +407,24 @@ def test_bands_wider_than_500_cells(gpu):
     eng.close()
     from real_time_audio_sync_amd import otw_eran as otw_mod
     drop = otw_mod.OnlineTimeWarping(ref, {"c": 700, "max_run_count": 3})
-    o = oracle.OtwOracle(ref, 700, 3, oracle.OTW)
+    o = oracle.OtwOracle(ref, 700, 3, oracle.OTW, keep_cost=True)
     for f in range(120):
         drop.insert(lives[0][:, f])
         o.insert(lives[0][:, f])
     assert np.array_equal(np.asarray(drop.path), o.path)
-    with pytest.raises(NotImplementedError, match="bands"):  # the dense mirror stops at c = 500: the drop-in says so up front
-        drop.acc_cost
-    with pytest.raises(nat.RtsyncError, match="dense"):      # ... and so does the C-ABI
-        drop._eng.replay_dense()
+    # the dense (2N x N) matrices at these widths (otw_eran.py:23,27): the plain kernel without rings, against the oracle's
+    assert np.array_equal(drop.acc_cost, o.acc_cost()) and np.array_equal(drop.cost, o.cost())
+    for c, n_ref, variant, mode in ((1100, 1250, "livenote", "set_live"), (2036, 2100, "otw", "insert")):
+        ref2, lives2 = synth.synth_batch(n_ref, 1, seed=900 + c)
+        eng = ob.BatchedOTW(ref2, c, 3, batch=1, variant=variant, dtype=torch.float32)
+        lv, ln = eng.pack(lives2)
+        eng.run(lv, ln, mode=mode)
+        acc, cost = eng.replay_dense()
+        o = oracle.OtwOracle(ref2, c, 3, vmap[variant], keep_cost=True)
+        (o.set_live if mode == "set_live" else o.run)(lives2[0])
+        assert np.array_equal(eng.path(0), o.path), (c, "path")
+        assert np.array_equal(acc[0].cpu().numpy(), o.acc_cost()) and np.array_equal(cost[0].cpu().numpy(), o.cost()), (c, "dense")
+        eng.close()
+        del acc, cost, o
     with pytest.raises(nat.RtsyncError):
         ob.BatchedOTW(ref, 2037, 3, batch=1, dtype=torch.float32)
