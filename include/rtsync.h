@@ -198,7 +198,7 @@ long long rts_chroma_num_frames(long long n_samples, int fft_len, int hop, int p
 /* A plan = window + twiddles + filterbank on the device.  `fb_host`: 12 x (fft_len/2+1) doubles, row
  * = pitch class (what librosa.filters.chroma(fs, fft_len) returns at chroma.py:69 / wtw.py:39);
  * `window_host`: fft_len doubles or NULL for np.hanning(fft_len) (chroma.py:39,:62).  fft_len: power
- * of two in [64, 4096] (the reference uses 4096, chroma.py:20). */
+ * of two in [64, 8192] (the reference uses 4096, chroma.py:20). */
 int rts_chroma_create(int fft_len, int hop, const double *window_host, const double *fb_host, rts_chroma **out);
 int rts_chroma_destroy(rts_chroma *h);
 

@@ -277,8 +277,9 @@ __global__ void __launch_bounds__(kChromaWG) chroma_frames_kernel(ChromaArgs g) 
                 const double x1 = (sidx + 1 >= 0 && sidx + 1 < g.n_samples) ? (double)ps1[r] : 0.0;
                 z[n] = make_double2(x0 * g.window[2 * n], x1 * g.window[2 * n + 1]);
             }
-            fetch_frame(round + 1 < kChromaFR / 2 ? (long long)frame + 2
-                                                  : (long long)frame0 + (long long)gridDim.x * kChromaFR + team);
+            // (within the group only: a prefetch kept across the projection -- 16 / 32 more live registers next to its 2 x 12
+            // accumulators and two weight sets -- is what used to push this kernel into scratch)
+            if (round + 1 < kChromaFR / 2) fetch_frame((long long)frame + 2);
             lds_barrier();  // LDS traffic only: the sample prefetch stays in flight
             CH_STAMP(1);
             // 2. Stockham autosort FFT, N2 points, in place via registers (read all, barrier, write all): one radix-2
@@ -379,12 +380,117 @@ __global__ void __launch_bounds__(kChromaWG) chroma_frames_kernel(ChromaArgs g) 
         //      is free now and serves as reduction scratch
         if (g.chroma_out)
             project_normalize<kChromaFR / 2>(g, spec, sstride, red, frame0, nf, team, 2, tid, [] { lds_barrier(); });
+        fetch_frame((long long)frame0 + (long long)gridDim.x * kChromaFR + team);  // the next group's first frame
         CH_STAMP(4);
     }
 #ifdef RTS_CHROMA_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == 0)
         for (int i = 0; i < 8; i++) g_chroma_stamps[i] = st_[i];
 #endif
+}
+
+// ---- fft_len = 8192 (wtw.py:27 takes any length; the reference's own configurations stop at 4096) --------------------
+// The 4096 packed complex points of one frame fill 64 KB of LDS, so a workgroup is ONE team of 256 threads with one
+// frame in flight; two consecutive frames share a pass over the (394 KB, L2-resident) filterbank.  No sample prefetch
+// and the twiddles come from the L2-resident table instead of an LDS copy (the work buffer, two power spectra and the
+// reduction scratch leave no room for it): this kernel exists for completeness, not for speed.
+constexpr int kBigFR = 2;
+
+template <typename ST>
+__global__ void __launch_bounds__(kChromaNT) chroma_frames_big_kernel(ChromaArgs g) {
+    extern __shared__ __align__(16) unsigned char ch_smem[];
+    const int L = g.L, N2 = L / 2, NQ = N2 / 2;  // 8192, 4096, 2048
+    const int sstride = N2 + 2;
+    const int tid = threadIdx.x;
+    double2 *z = reinterpret_cast<double2 *>(ch_smem);             // [N2] FFT work buffer; reduction scratch afterwards
+    double *spec = reinterpret_cast<double *>(z + N2);             // [kBigFR][sstride]
+    auto tw = [&](int t) {  // t < N2: quarter-circle symmetry as in the kernels above, from the table in L2
+        const double2 w = g.twiddle[t & (NQ - 1)];
+        return (t & NQ) ? make_double2(w.y, -w.x) : w;
+    };
+    const int sb = blockIdx.y;
+    if (g.n_frames_b) {
+        g.n_frames = g.n_frames_b[sb];
+        g.n_samples = g.n_samples_b[sb];
+        g.samples = reinterpret_cast<const ST *>(g.samples) + (long long)sb * g.sample_stride;
+        const long long oo = (long long)sb * g.out_frames_stride * kCh;
+        g.chroma_out = g.out_f64 ? (void *)(reinterpret_cast<double *>(g.chroma_out) + oo)
+                                 : (void *)(reinterpret_cast<float *>(g.chroma_out) + oo);
+    }
+    constexpr int kMaxBf4 = 4;  // N2/4/256 butterflies per thread and stage
+    for (int frame0 = blockIdx.x * kBigFR; frame0 < g.n_frames; frame0 += gridDim.x * kBigFR) {
+        const int nf = (g.n_frames - frame0 < kBigFR) ? g.n_frames - frame0 : kBigFR;
+        for (int f = 0; f < nf; f++) {
+            const int frame = frame0 + f;
+            // 1. window, pack as complex (out-of-range samples: the zero padding on the left, chroma.py:49)
+            for (int n = tid; n < N2; n += kChromaNT) {
+                const long long sidx = g.frame_offset + (long long)frame * g.hop + 2 * n;
+                const double x0 = (sidx >= 0 && sidx < g.n_samples) ? (double)reinterpret_cast<const ST *>(g.samples)[sidx] : 0.0;
+                const double x1 = (sidx + 1 >= 0 && sidx + 1 < g.n_samples) ? (double)reinterpret_cast<const ST *>(g.samples)[sidx + 1] : 0.0;
+                z[n] = make_double2(x0 * g.window[2 * n], x1 * g.window[2 * n + 1]);
+            }
+            __syncthreads();
+            // 2. Stockham radix-4 stages, in place via registers (log2(4096) is even: no radix-2 stage)
+            const int q = N2 / 4;
+            for (int p = 1; p < N2; p <<= 2) {
+                double2 o[kMaxBf4][4];
+                int jj[kMaxBf4];
+                const int tstep = N2 / (2 * p);
+#pragma unroll
+                for (int r = 0; r < kMaxBf4; r++) {
+                    const int i = tid + r * kChromaNT;
+                    const int k = i & (p - 1);
+                    const int t1 = k * tstep, t2 = 2 * t1, t3 = 3 * t1;
+                    const double2 w1 = tw(t1), w2 = tw(t2);
+                    double2 w3 = tw(t3 & (N2 - 1));
+                    if (t3 >= N2) w3 = make_double2(-w3.x, -w3.y);
+                    const double2 u0 = z[i];
+                    const double2 u1 = cmul(w1, z[i + q]);
+                    const double2 u2 = cmul(w2, z[i + 2 * q]);
+                    const double2 u3 = cmul(w3, z[i + 3 * q]);
+                    const double2 a0 = make_double2(u0.x + u2.x, u0.y + u2.y);
+                    const double2 a1 = make_double2(u0.x - u2.x, u0.y - u2.y);
+                    const double2 a2 = make_double2(u1.x + u3.x, u1.y + u3.y);
+                    const double2 a3 = make_double2(u1.y - u3.y, -(u1.x - u3.x));
+                    o[r][0] = make_double2(a0.x + a2.x, a0.y + a2.y);
+                    o[r][1] = make_double2(a1.x + a3.x, a1.y + a3.y);
+                    o[r][2] = make_double2(a0.x - a2.x, a0.y - a2.y);
+                    o[r][3] = make_double2(a1.x - a3.x, a1.y - a3.y);
+                    jj[r] = ((i - k) << 2) + k;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kMaxBf4; r++) {
+                    z[jj[r]] = o[r][0];
+                    z[jj[r] + p] = o[r][1];
+                    z[jj[r] + 2 * p] = o[r][2];
+                    z[jj[r] + 3 * p] = o[r][3];
+                }
+                __syncthreads();
+            }
+            // 3. untangle -> rfft bins, power spectrum
+            const int nb = N2 + 1;
+            double *sp = spec + (size_t)f * sstride;
+            for (int k = tid; k < nb; k += kChromaNT) {
+                const double2 a = z[k & (N2 - 1)];
+                const double2 bq = z[(N2 - k) & (N2 - 1)];
+                const double2 b = make_double2(bq.x, -bq.y);
+                const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+                const double2 dm = make_double2(a.x - b.x, a.y - b.y);
+                const double2 od = make_double2(0.5 * dm.y, -0.5 * dm.x);
+                const double2 w = (k < N2) ? tw(k) : make_double2(-1.0, 0.0);
+                const double2 wo = cmul(w, od);
+                const double2 x = make_double2(e.x + wo.x, e.y + wo.y);
+                if (g.stft_out) g.stft_out[(size_t)frame * nb + k] = x;
+                sp[k] = x.x * x.x + x.y * x.y;
+            }
+            __syncthreads();
+        }
+        if (g.chroma_out)
+            project_normalize<kBigFR>(g, spec, sstride, reinterpret_cast<double *>(z), frame0, nf, 0, 1, tid, [] { __syncthreads(); });
+        else
+            __syncthreads();
+    }
 }
 
 // ---- fft_len = 4096 (the reference's only setting, chroma.py:20 / wtw.py:27): a specialised kernel -----------------
@@ -642,7 +748,7 @@ struct rts_chroma {
     double2 *twiddle;  // device [L/2]
     double *fb;        // device [12][L/2+1]
     double *fbt;       // device [L/2+1][12]
-    size_t smem_frames, smem_frames4096, smem_project;
+    size_t smem_frames, smem_frames4096, smem_frames_big, smem_project;
     int device;  // the HIP device the plan's tables live on
     int cus;     // its compute units
 };
@@ -679,8 +785,8 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
     if (!out) return set_error(RTS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!fb_host) return set_error(RTS_ERR_INVALID, "fb_host is NULL (12 x (fft_len/2+1) filterbank)");
-    if (fft_len < 64 || fft_len > 4096 || (fft_len & (fft_len - 1)))
-        return set_error(RTS_ERR_UNSUPPORTED, "fft_len must be a power of two in [64, 4096] (got %d)", fft_len);
+    if (fft_len < 64 || fft_len > 8192 || (fft_len & (fft_len - 1)))
+        return set_error(RTS_ERR_UNSUPPORTED, "fft_len must be a power of two in [64, 8192] (got %d): a frame's FFT runs in LDS", fft_len);
     if (hop < 1) return set_error(RTS_ERR_INVALID, "hop must be >= 1");
     rts_chroma *h = (rts_chroma *)calloc(1, sizeof(rts_chroma));
     if (!h) return set_error(RTS_ERR_INVALID, "out of host memory");
@@ -723,6 +829,7 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
     h->smem_frames = sizeof(double2) * (2 * (size_t)N2 + N2 / 2) + sizeof(double) * (size_t)kChromaFR * (N2 + 2) +
                      ((2 * N2 >= 3264) ? 0 : sizeof(double) * 2 * 3264) + 64;
     h->smem_project = sizeof(double) * ((size_t)kChromaFR * (nb + 1) + 3264) + 64;
+    h->smem_frames_big = sizeof(double2) * (size_t)N2 + sizeof(double) * (size_t)kBigFR * (N2 + 2) + 64;
     // per plan, i.e. on the device that is current now (the attribute is per device)
     h->smem_frames4096 = sizeof(double2) * (2 * (size_t)c4k::ZSLOTS + c4k::NQ) + sizeof(double) * (size_t)kChromaFR * c4k::SSTRIDE + 64;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames4096_kernel<float>),
@@ -735,6 +842,12 @@ int rts_chroma_create(int fft_len, int hop, const double *window_host, const dou
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_big_kernel<float>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_frames_big_kernel<double>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chroma_project_kernel),
@@ -807,6 +920,13 @@ int rts_chroma_frames(rts_chroma *h, const void *samples_dev, int sample_dtype, 
             hipLaunchKernelGGL(chroma_frames4096_kernel<double>, dim3(grid), dim3(kChromaWG), h->smem_frames4096, (hipStream_t)stream, g);
         else
             hipLaunchKernelGGL(chroma_frames4096_kernel<float>, dim3(grid), dim3(kChromaWG), h->smem_frames4096, (hipStream_t)stream, g);
+    } else if (h->L > 4096) {
+        const int groups_big = (n_frames + kBigFR - 1) / kBigFR;
+        const int grid_big = groups_big < 4 * h->cus ? groups_big : 4 * h->cus;
+        if (g.samples_f64)
+            hipLaunchKernelGGL(chroma_frames_big_kernel<double>, dim3(grid_big), dim3(kChromaNT), h->smem_frames_big, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL(chroma_frames_big_kernel<float>, dim3(grid_big), dim3(kChromaNT), h->smem_frames_big, (hipStream_t)stream, g);
     } else if (g.samples_f64) {
         hipLaunchKernelGGL(chroma_frames_kernel<double>, dim3(grid), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
     } else {
@@ -855,6 +975,13 @@ int rts_chroma_frames_batch(rts_chroma *h, const void *samples_dev, int sample_d
             hipLaunchKernelGGL(chroma_frames4096_kernel<double>, dim3(gx, B), dim3(kChromaWG), h->smem_frames4096, (hipStream_t)stream, g);
         else
             hipLaunchKernelGGL(chroma_frames4096_kernel<float>, dim3(gx, B), dim3(kChromaWG), h->smem_frames4096, (hipStream_t)stream, g);
+    } else if (h->L > 4096) {
+        const int groups_big = (n_frames_max + kBigFR - 1) / kBigFR;
+        const int gx_big = groups_big < 64 ? groups_big : 64;
+        if (g.samples_f64)
+            hipLaunchKernelGGL(chroma_frames_big_kernel<double>, dim3(gx_big, B), dim3(kChromaNT), h->smem_frames_big, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL(chroma_frames_big_kernel<float>, dim3(gx_big, B), dim3(kChromaNT), h->smem_frames_big, (hipStream_t)stream, g);
     } else if (g.samples_f64) {
         hipLaunchKernelGGL(chroma_frames_kernel<double>, dim3(gx, B), dim3(kChromaWG), h->smem_frames, (hipStream_t)stream, g);
     } else {

@@ -2073,23 +2073,24 @@ static int launch_advance(rts_otw *h, const OtwArgs &args, int B, hipStream_t s)
             if (args.spec) return launch_advance_d<W, NW, false, LiveFromGlobal, true>(h, args, B, s);
         }
         return set_error(RTS_ERR_UNSUPPORTED, "band widths above 500 (c=%d) run only on the pipelined 8-wave kernel", h->c);
-    }
-    if (args.dense_acc) return launch_advance_d<W, NW, true, double, false>(h, args, B, s);
-    // float32 rings only when both inputs are float32: every value then widens back exactly
-    const bool f32 = !args.ref_f64 && !args.live_f64;
-    if constexpr (NW >= 8) {
-        if (args.spec) {
-            // two streams per CU or more: the 73-register flavour, three workgroups per CU
-            if (B >= h->tp_from * h->cus && B > 0) return launch_advance_d<W, NW, false, LiveFromGlobalLean, true>(h, args, B, s);
-            if (f32) return launch_advance_d<W, NW, false, float, true>(h, args, B, s);
-            // float64 features: the ring (one workgroup per CU at W = 512) while every stream has a CU to itself
-            // (B = 64: 4.67 vs 4.93 ms), no ring and up to four workgroups per CU beyond
-            return (B <= h->cus) ? launch_advance_d<W, NW, false, double, true>(h, args, B, s)
-                                 : launch_advance_d<W, NW, false, LiveFromGlobal, true>(h, args, B, s);
+    } else {  // (an else branch, so that none of the ring kernels below is instantiated for the wide windows)
+        if (args.dense_acc) return launch_advance_d<W, NW, true, double, false>(h, args, B, s);
+        // float32 rings only when both inputs are float32: every value then widens back exactly
+        const bool f32 = !args.ref_f64 && !args.live_f64;
+        if constexpr (NW >= 8) {
+            if (args.spec) {
+                // two streams per CU or more: the 73-register flavour, three workgroups per CU
+                if (B >= h->tp_from * h->cus && B > 0) return launch_advance_d<W, NW, false, LiveFromGlobalLean, true>(h, args, B, s);
+                if (f32) return launch_advance_d<W, NW, false, float, true>(h, args, B, s);
+                // float64 features: the ring (one workgroup per CU at W = 512) while every stream has a CU to itself
+                // (B = 64: 4.67 vs 4.93 ms), no ring and up to four workgroups per CU beyond
+                return (B <= h->cus) ? launch_advance_d<W, NW, false, double, true>(h, args, B, s)
+                                     : launch_advance_d<W, NW, false, LiveFromGlobal, true>(h, args, B, s);
+            }
         }
+        return f32 ? launch_advance_d<W, NW, false, float, false>(h, args, B, s)
+                   : launch_advance_d<W, NW, false, double, false>(h, args, B, s);
     }
-    return f32 ? launch_advance_d<W, NW, false, float, false>(h, args, B, s)
-               : launch_advance_d<W, NW, false, double, false>(h, args, B, s);
 }
 
 template <int W>

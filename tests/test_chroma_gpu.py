@@ -105,7 +105,7 @@ def test_other_hop_and_fft_sizes(mods):
     chroma, co = mods
     rs = np.random.RandomState(1)
     x = (rs.rand(30000) - 0.5).astype(np.float32)
-    for L, H in ((4096, 512), (2048, 1024), (1024, 256), (256, 64)):
+    for L, H in ((4096, 512), (2048, 1024), (1024, 256), (256, 64), (8192, 2048), (8192, 4096)):
         plan = chroma.ChromaPlan(L, H, 22050)
         ch, st = plan.frames(torch.from_numpy(x).to(plan.device), pad_left=L // 2, want_stft=True)
         ost = co.create_stft(x, L, H)
@@ -118,7 +118,7 @@ def test_other_hop_and_fft_sizes(mods):
         plan.close()
     from real_time_audio_sync_amd import _native as nat
     with pytest.raises(nat.RtsyncError):
-        chroma.ChromaPlan(8192, 2048, 22050)   # 8192-point frames do not fit the LDS-resident FFT
+        chroma.ChromaPlan(16384, 2048, 22050)   # 16384-point frames do not fit the LDS-resident FFT
 
 
 def test_create_stft_against_reference_columns(mods, chopin_audio):
