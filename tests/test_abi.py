@@ -70,6 +70,13 @@ def test_no_lds_result_is_used_before_its_wait(nat):
                   "\ts_waitcnt lgkmcnt(0)\n\tv_add_f64 v[10:11], v[6:7], v[4:5]\n\ts_endpgm\n"
     late = head + "\tds_read_b64 v[4:5], v1\n\tds_read_b64 v[6:7], v1\n\ts_waitcnt lgkmcnt(1)\n\tv_mov_b32_e32 v9, v7\n\ts_endpgm\n"
     assert len(chk.check(bad)[2]) == 1 and len(chk.check(good)[2]) == 0 and len(chk.check(late)[2]) == 1
-    kernels, loads, violations = chk.check(chk.disassemble(nat.SO_PATH))
+    text = chk.disassemble(nat.SO_PATH)
+    kernels, loads, violations = chk.check(text)
     assert kernels >= 50 and loads >= 5000      # every instantiation of every kernel was looked at
     assert not violations, violations[:5]
+    # the DPP read-after-VALU-write hazard (two wait states), same idea: the scanner on a made-up case, then the library
+    hz = head + "\tv_min_f64 v[0:1], v[0:1], v[2:3]\n\tv_mov_b32_dpp v4, v0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_endpgm\n"
+    ok = head + "\tv_min_f64 v[0:1], v[0:1], v[2:3]\n\ts_nop 1\n\tv_mov_b32_dpp v4, v0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_endpgm\n"
+    assert len(chk.check_dpp(hz)[1]) == 1 and len(chk.check_dpp(ok)[1]) == 0
+    n_dpp, bad_dpp = chk.check_dpp(text)
+    assert n_dpp >= 1000 and not bad_dpp, bad_dpp[:5]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Build-time check on librtsync.so's device code: no instruction reads the destination of an LDS load before an
-s_waitcnt that retires it.
+"""Build-time checks on librtsync.so's device code: (1) no instruction reads the destination of an LDS load before an
+s_waitcnt that retires it; (2) no DPP instruction reads a VGPR within two wait states of the VALU write that produced it
+(check_dpp below).
 
 Why: csrc/otw.hip issues some LDS reads through inline asm (immediate-offset ds_read_b64 in strip_chain); the compiler's
 own waitcnt insertion does not see those, the code waits for them explicitly (chain_wait) behind a 16-way switch.  That is
@@ -118,14 +119,61 @@ def check(asm_text, only=None):
     return kernels, loads, bad
 
 
+_DPP_CTRL = (" wave_sh", " wave_ro", " row_sh", " row_ro", " row_bcast", " row_mirror", " row_half_mirror", " quad_perm", " row_newbcast")
+
+
+def check_dpp(asm_text):
+    """Second property of the generated code: a DPP instruction reads its source VGPR no sooner than two wait states
+    after a VALU instruction wrote it (gfx940/gfx950 manual hazard).  The compiler places the s_nop itself -- also after
+    inline asm that defines the register (csrc's v_min_f64) -- but not *inside* inline asm, and a hand-written DPP move
+    would need its own; this scan keeps both honest.  -> (DPP instructions seen, violations)."""
+    seen = 0
+    bad = []
+    name = None
+    hist = []
+    for line in asm_text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            name, hist = m.group(1), []
+            continue
+        ins = line.split("//")[0].strip()
+        if not ins or name is None:
+            continue
+        op, _, rest = ins.partition(" ")
+        if op.startswith("v_") and any(c in rest for c in _DPP_CTRL):
+            seen += 1
+            srcs = rest.split(",", 1)[1] if "," in rest else ""
+            for c in _DPP_CTRL:
+                srcs = srcs.split(c)[0]
+            src = _regs(srcs)
+            ws = 0
+            for pop, prest in reversed(hist):
+                if ws >= 2:
+                    break
+                if pop == "s_nop":
+                    ws += int(prest.strip() or "0", 0) + 1
+                    continue
+                if pop.startswith("v_") and _regs(prest.split(",")[0]) & src:
+                    bad.append((name, "%s %s" % (pop, prest), ins))
+                ws += 1
+        hist.append((op, rest))
+        hist = hist[-4:]
+    return seen, bad
+
+
 def main():
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "real_time_audio_sync_amd", "librtsync.so")
     only = sys.argv[2] if len(sys.argv) > 2 else None
-    kernels, loads, bad = check(disassemble(so), only)
+    text = disassemble(so)
+    kernels, loads, bad = check(text, only)
     print("%d kernels, %d LDS loads scanned, %d violations" % (kernels, loads, len(bad)))
     for name, ins, regs in bad[:40]:
         print("  %s\n      %s   <- uses v%s before its LDS data is waited for" % (name[:100], ins, regs))
-    return 1 if bad else 0
+    n_dpp, bad_dpp = check_dpp(text)
+    print("%d DPP instructions scanned, %d read a VGPR within two wait states of its VALU write" % (n_dpp, len(bad_dpp)))
+    for name, w, r in bad_dpp[:40]:
+        print("  %s\n      %s\n      %s" % (name[:100], w, r))
+    return 1 if bad or bad_dpp else 0
 
 
 if __name__ == "__main__":
