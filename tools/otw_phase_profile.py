@@ -13,7 +13,8 @@ def build():
     so = os.path.join(DIAG, "librtsync_diag.so")
     src = [os.path.join(ROOT, "real_time_audio_sync_amd", "csrc", f) for f in ("common.cpp", "otw.hip")]
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-DRTS_OTW_STAMPS=%s" % os.environ.get("RTS_DIAG_LEVEL", "1"), "-o", so]
+           "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-sched-strategy=max-ilp",  # as _build.PER_SOURCE_FLAGS["otw.hip"]
+           "-DRTS_OTW_STAMPS=%s" % os.environ.get("RTS_DIAG_LEVEL", "1"), "-o", so]
     for s in src:
         cmd += ["-x", "hip", s]
     subprocess.check_call(cmd)
