@@ -1297,7 +1297,10 @@ __device__ __forceinline__ OtwSettled otw_settle_hit(double *R, double *C, const
 #endif
 
 template <int W, int NW, bool DENSE, typename RT, bool SPEC>
-__global__ void __launch_bounds__(64 * NW) otw_advance_kernel(OtwArgs a) {
+// (the throughput flavour exists for its residency -- three workgroups of eight waves per CU, i.e. at most 80 VGPRs: said to
+// the compiler here, because the ILP-first scheduling this file is built with otherwise spends 87)
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(kThroughput<RT> ? 6 : 1)))
+otw_advance_kernel(OtwArgs a) {
     static_assert(!SPEC || (NW >= 8 && !DENSE), "the pipelined kernel needs 8 waves and no dense mirror");
     constexpr int NT = 64 * NW;
     // Waves >= HW0 pre-compute the next step's cell costs while waves 0/1 run the chains (pipelined kernel:

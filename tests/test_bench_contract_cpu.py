@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r03c_bench_final.json, produced by `python bench.py` on an MI355X)
+"""The committed bench line (profiles/r03d_bench_final.json, produced by `python bench.py` on an MI355X)
 carries every field the driver's contract asks for, and its numbers are self-consistent."""
 import json
 import os
@@ -7,7 +7,7 @@ from conftest import ROOT
 
 
 def test_bench_line_contract():
-    r = json.load(open(os.path.join(ROOT, "profiles", "r03c_bench_final.json")))
+    r = json.load(open(os.path.join(ROOT, "profiles", "r03d_bench_final.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert r["metric"] == base["metric"] and r["unit"] == "frames/s"
     for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

@@ -1,7 +1,7 @@
 #!/bin/bash
-# One pass over everything profiles/<tag>_* holds (run on the GPU box: gpurun -- bash tools/collect_all.sh r03c; build tools/_diag/librtsync_diag.so with RTS_DIAG_LEVEL=2 python tools/otw_phase_profile.py --build first).
+# One pass over everything profiles/<tag>_* holds (run on the GPU box: gpurun -- bash tools/collect_all.sh r03d; build tools/_diag/librtsync_diag.so with RTS_DIAG_LEVEL=2 python tools/otw_phase_profile.py --build first).
 set -e
-TAG=${1:-r03c}
+TAG=${1:-r03d}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
