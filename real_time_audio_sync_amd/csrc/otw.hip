@@ -1138,15 +1138,21 @@ __device__ __forceinline__ void otw_spec_strip(const double *Dv, const double *b
 
 // The last cell of a shadow strip, in the chain's own order: min(min(side + d, diag + 2d), previous cell + d).  `side`
 // is the old band's slot at `pos` (up for a row strip, left for a column strip), `diag` its slot at pos-1.
-template <int W>
-__device__ __forceinline__ double otw_last_cell(const double *band, int pos, int k1, double side_v, double diag_v, double d,
-                                                double sentinel) {
+// (`prev_raw`: the band's slot at pos - 1, or at pos when the strip has only this cell -- read by the caller, so that wave 0
+// can fetch it in the same LDS round trip as everything else it needs for the step)
+__device__ __forceinline__ double otw_last_cell_from(double prev_raw, int pos, int k1, double side_v, double diag_v, double d,
+                                                     double sentinel) {
     const double inf = INFINITY;
-    const int n = pos - k1;  // the strip is [k1, pos]
-    const double prev_raw = band[swz<W>(pos - (n > 0 ? 1 : 0))];
+    const int n = pos - k1;
     const double prev = (n > 0) ? prev_raw : ((k1 > 0) ? sentinel : inf);
     const double diag = (pos > 0) ? diag_v + 2 * d : inf;
     return vmin(vmin(side_v + d, diag), prev + d);
+}
+template <int W>
+__device__ __forceinline__ double otw_last_cell(const double *band, int pos, int k1, double side_v, double diag_v, double d,
+                                                double sentinel) {
+    const int n = pos - k1;  // the strip is [k1, pos]
+    return otw_last_cell_from(band[swz<W>(pos - (n > 0 ? 1 : 0))], pos, k1, side_v, diag_v, d, sentinel);
 }
 
 // A Both step as a hit (wave 0).  While the band is still filling (t, j <= c-2: both strips start at 0, exactly like
@@ -1163,17 +1169,25 @@ __device__ __forceinline__ OtwSettled otw_settle_hit_both(double *R, double *C, 
         if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
         k.pend_dir = -2;
     }
-    const double d1 = rfl(exr->d), d2 = rfl(exc->d), d3 = rfl(exc->d2);
-    double rmin = rfl(exr->min), cmin = rfl(exc->min);
-    int ridx = __builtin_amdgcn_readfirstlane(exr->idx), cidx = __builtin_amdgcn_readfirstlane(exc->idx);
+    // every LDS word the step needs in one round trip: the two speculation records and the two band slots in front of the
+    // strips' last cells (the unconditional readfirstlane keeps the compiler from sinking those two reads into the branch
+    // that uses them, i.e. behind the first wait: that was a second and a third round trip per Both step)
+    const int k1r_ = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, k1c_ = (pt - c + 1 > 0) ? pt - c + 1 : 0;
+    const double pra_raw = R[swz<W>(j0 - (j0 - k1r_ > 0 ? 1 : 0))], prb_raw = C[swz<W>(t0 - (t0 - k1c_ > 0 ? 1 : 0))];
+    const double d1_raw = exr->d, d2_raw = exc->d, d3_raw = exc->d2, rmin_raw = exr->min, cmin_raw = exc->min;
+    const int ridx_raw = exr->idx, cidx_raw = exc->idx;
+    const double d1 = rfl(d1_raw), d2 = rfl(d2_raw), d3 = rfl(d3_raw);
+    double rmin = rfl(rmin_raw), cmin = rfl(cmin_raw);
+    int ridx = __builtin_amdgcn_readfirstlane(ridx_raw), cidx = __builtin_amdgcn_readfirstlane(cidx_raw);
+    const double pra = rfl(pra_raw), prb = rfl(prb_raw);
     // the Both step's strips: row pt over [k1r, j0] -- the speculated row strip plus its last cell; column jn over
     // [k1c, pt-1] -- the speculated column strip [k1c_s, pt-2] without its first cell once the band is full
     // (k1c = k1c_s + 1; the speculation's flag vouches that dropping it changes nothing else) plus its last cell
     const int k1r = (j0 - c + 1 > 0) ? j0 - c + 1 : 0, k1c = (pt - c + 1 > 0) ? pt - c + 1 : 0;
     const int lo_r = (jn - c + 1 > 0) ? jn - c + 1 : 0;  // decide() looks at row pt from here on
     const int k1c_s = (t0 - c + 1 > 0) ? t0 - c + 1 : 0;
-    const double a = rfl(otw_last_cell<W>(R, j0, k1r, k.cA, k.cL, d1, sentinel));
-    const double b = rfl(otw_last_cell<W>(C, t0, k1c, k.cA, k.cU, d2, sentinel));
+    const double a = rfl(otw_last_cell_from(pra, j0, k1r, k.cA, k.cL, d1, sentinel));
+    const double b = rfl(otw_last_cell_from(prb, t0, k1c, k.cA, k.cU, d2, sentinel));
     const double pa = k.cA + 2 * d3;  // acc[pt-1][j0] + 2 d(pt, jn)
     const double av = vmin(a + d3, pa);
     const double cl = vmin(av, b + d3);
@@ -1248,12 +1262,15 @@ __device__ __forceinline__ OtwSettled otw_settle_hit(double *R, double *C, const
         if (k.pend_dir != RTS_DIR_BOTH) k.prev = k.pend_dir;
         k.pend_dir = -2;
     }
-    // four independent LDS reads, one wait
+    // four independent LDS reads (a scheduling barrier behind them, which makes it one wait instead of two, measured neutral)
     const double prev_raw = band[swz<W>(pos - (n > 0 ? 1 : 0))];
-    const double d = rfl(ex->d);
-    const double smin = rfl(ex->min);
-    const int sidx = __builtin_amdgcn_readfirstlane(ex->idx);
-    const double prev = (n > 0) ? rfl(prev_raw) : ((k1 > 0) ? sentinel : inf);
+    const double d_raw = ex->d, smin_raw = ex->min;
+    const int sidx_raw = ex->idx;
+    const double d = rfl(d_raw);
+    const double smin = rfl(smin_raw);
+    const int sidx = __builtin_amdgcn_readfirstlane(sidx_raw);
+    const double prev_s = rfl(prev_raw);  // unconditional: keeps the read in the round trip above (see otw_settle_hit_both)
+    const double prev = (n > 0) ? prev_s : ((k1 > 0) ? sentinel : inf);
     // row hit: cell (pt, j0), "side" = up; column hit: cell (pt, jn), "side" = left -- in the chain's order
     // min(min(side + d, diag + 2d), previous cell of the strip + d)
     const double side = k.cA + d;
