@@ -291,11 +291,16 @@ constexpr int kWinKW = 12;       // code words per lane: 64 + 127 - 1 steps at m
 constexpr int kWinPadFront = 64;  // doubles in front of / behind the cost matrix: lanes that are not on a valid cell read
 constexpr int kWinPadBack = 208;  // (and ignore) whatever their row pointer + step lands on
 
+// wave 0's bottom row (bot / botx): 64 slots in front and 32 behind for the steps at which lane 63 is not on a valid cell,
+// and 80 more where every other lane's share of the same unconditional store lands
+constexpr int kWinBotFront = 64, kWinBotBack = 32, kWinBotDummy = 80;
+constexpr int kWinBotPad = kWinBotFront + kWinBotBack + kWinBotDummy;
+
 __host__ __device__ inline int win_ldc(int W) { return (W | 1) + 1; }  // even > W: lanes a row apart hit different LDS banks
 __host__ __device__ inline size_t win_lds_bytes(int W) {
     const size_t feat = sizeof(double) * ((size_t)W * kWF + (size_t)W);                    // xs, nx
-    const size_t walk = sizeof(uint32_t) * 2 * kWinKW * 64 + sizeof(double) * (3 * (size_t)W + 32) +  // codes; row 0, column 0 (padded), bottom row of wave 0
-                        sizeof(int32_t) * (size_t)W + sizeof(int32_t) * 4 * (size_t)W;     // its crossing columns; sub-path
+    const size_t walk = sizeof(uint32_t) * 2 * kWinKW * 64 + sizeof(double) * (3 * (size_t)W + 32 + kWinBotPad) +  // codes; row 0, column 0 (padded), bottom row of wave 0 (padded)
+                        sizeof(int32_t) * ((size_t)W + kWinBotPad) + sizeof(int32_t) * 4 * (size_t)W;  // its crossing columns (padded); sub-path
     return sizeof(double) * ((size_t)W * win_ldc(W) + kWinPadFront + kWinPadBack) + feat + walk + 128;
 }
 
@@ -330,9 +335,11 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
     uint32_t *codes = reinterpret_cast<uint32_t *>(nx + W);                       // [2][kWinKW][64]
     double *row0 = reinterpret_cast<double *>(codes + 2 * kWinKW * 64);           // [W + 16] D[0][:]
     double *col0 = row0 + W + 16;                                                 // [W + 16] D[:][0]
-    double *bot = col0 + W + 16;                                                  // [W] D[64][:] (wave 0's last row)
-    int32_t *botx = reinterpret_cast<int32_t *>(bot + W);                         // [W] ... and its crossing columns
-    int32_t *sub = botx + W;                                                      // [2W][2], reversed
+    double *bot = col0 + W + 16 + kWinBotFront;                                   // [W] D[64][:] (wave 0's last row), padded
+    double *bot_dummy = bot + W + kWinBotBack;                                    // [80]
+    int32_t *botx = reinterpret_cast<int32_t *>(bot_dummy + kWinBotDummy) + kWinBotFront;  // [W] ... and its crossing columns, padded
+    int32_t *botx_dummy = botx + W + kWinBotBack;                                 // [80]
+    int32_t *sub = botx_dummy + kWinBotDummy;                                     // [2W][2], reversed
 
     int32_t *st = g.state + (size_t)b * 8;
     const double *live = g.live + (size_t)b * g.N * kWF;
@@ -531,6 +538,9 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
                 if (R > 1) lds_barrier();  // wave 1 reads bottom-row values wave 0 wrote at least one round ago
                 const int kb = k - 5 * r;
                 if (kb < 0 || kb >= blocks) continue;  // wave-uniform
+#ifdef RTS_WIN_STAMPS
+                const long long blk_t0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
                 // the block's 16 costs and 16 values of the row above lane 0 first (independent of the recurrence: one
                 // LDS round trip per block instead of one per step)
                 double cbuf[16], ubuf[16];
@@ -542,6 +552,14 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
                     ubuf[q] = upin[(t + 1 < m) ? t + 1 : 0];
                     uxbuf[q] = (R > 1 && r > 0) ? botx[(t + 1 < m) ? t + 1 : 0] : 0;
                 }
+                // Two DP waves: wave 0's bottom row goes to LDS for wave 1 WITHOUT a branch in the step -- a branch ends the
+                // basic block, and with it the compiler's freedom to overlap one step's selects with the next step's
+                // chain (measured: 228 cycles per step with the branch, 139 in the one-wave kernel that has none).  So
+                // every lane of both waves stores every step: lane 63 of wave 0 to bot[column] (column = t - 62 is hit
+                // exactly once per window; steps at which the lane is not on a valid cell land in the padding), everybody
+                // else to a scratch strip.
+                double *bw = (r == 0 && lane == 63) ? bot + (16 * kb - 62) : bot_dummy + lane;
+                int32_t *bxw = (r == 0 && lane == 63) ? botx + (16 * kb - 62) : botx_dummy + lane;
                 uint32_t word = 0;
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
@@ -564,15 +582,16 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
                         dlast_v = dv;                                      // D[i][j-1] of the next step
                         xl = xn;
                     }
-                    if (valid) {
-                        if (R > 1 && r == 0 && lane == 63) {
-                            bot[jj + 1] = dv;
-                            botx[jj + 1] = xn;
-                        }
-                        if (STAGE) dout[jj + 1] = dv;
+                    if constexpr (R > 1) {
+                        bw[q] = dv;
+                        bxw[q] = xn;
                     }
+                    if (STAGE && valid) dout[jj + 1] = dv;
                 }
                 codes[((size_t)r * kWinKW + kb) * 64 + lane] = word;
+#ifdef RTS_WIN_STAMPS
+                if (b == 0 && lane == 0 && r < 2) g_win_stamps[6 + r] += (long long)__builtin_amdgcn_s_memtime() - blk_t0_;  // a DP wave's own block time
+#endif
             }
             if (r < R && lane < rows && i == n - 1) sh[2] = xl;  // the last cell's crossing column
         }
@@ -896,7 +915,7 @@ int rts_wtw_create(const double *chroma_ref_dev, int F, int M, int B, int win_fr
     bool win = W <= kWinAutoW;
     if (const char *e = getenv("RTS_WTW_WIN")) win = W <= kWinMaxW && atoi(e) != 0;
     if (getenv("RTS_WTW_BIG_FROM")) win = false;
-    h->use_win = win ? (W <= 65 ? 1 : 2) : 0;  // interior rows 1 .. W-1: one wave up to 65 frames
+    h->use_win = win ? ((W <= 65 && !getenv("RTS_WIN_FORCE_R2")) ? 1 : 2) : 0;  // interior rows 1 .. W-1: one wave up to 65 frames (RTS_WIN_FORCE_R2: tests)
     const bool big = !win && W > big_from;
     h->use_big = big;
     if (big) {

@@ -54,12 +54,15 @@ def test_windows_against_reference_vectors(wtw_window_golden, wtw_path):
         eng.close()
 
 
-@pytest.fixture(params=["win", "older"])
+@pytest.fixture(params=["win", "win_two_waves", "older"])
 def wtw_path(request, monkeypatch):
     """Windows of at most 128 frames can run on wtw_win_kernel (every window of a push in one launch; the default up to
     104 frames, forced up to 128 here); RTS_WTW_WIN=0 selects the older kernels (anti-diagonal sweep up to 64 frames,
-    strip DP above), which stay covered this way."""
+    strip DP above), which stay covered this way.  "win_two_waves" sends windows of 65 frames or fewer through the
+    two-wave form of the kernel as well (RTS_WIN_FORCE_R2: its second DP wave then has no rows)."""
     monkeypatch.setenv("RTS_WTW_WIN", "0" if request.param == "older" else "1")
+    if request.param == "win_two_waves":
+        monkeypatch.setenv("RTS_WIN_FORCE_R2", "1")
     return request.param
 
 

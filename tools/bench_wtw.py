@@ -58,7 +58,8 @@ def main():
                 eng_lib().rts_wtw_read_win_stamps(buf)
                 wn = max(buf[5], 1)
                 print(json.dumps(dict(W=W, stamps_cycles_per_window=dict(phase_a_wave0=buf[0] / wn, running_sums=buf[1] / wn, dp=buf[2] / wn,
-                                                                          walk_handover_wave0=buf[3] / wn, costs_wave1=buf[4] / wn), windows_stream0=int(buf[5]))), flush=True)
+                                                                          walk_handover_wave0=buf[3] / wn, costs_wave1=buf[4] / wn,
+                                                                          dp_blocks_own_wave0=buf[6] / wn, dp_blocks_own_wave1=buf[7] / wn), windows_stream0=int(buf[5]))), flush=True)
             eng.close()
         assert all(np.array_equal(a, b) for a, b in zip(paths["default"], paths["RTS_WTW_WIN=0"])), W
 
