@@ -320,6 +320,57 @@ __device__ long long g_win_stamps[8];
     } while (0)
 #endif
 
+// One block of 16 DP steps of wtw_win_kernel, as a macro so that each DP wave gets its own straight-line copy (W1: this is the
+// second wave -- it fetches the crossing columns of wave 0's bottom row for its lane 0 and has no row to hand on; the first
+// wave does the opposite).  Not a lambda: inside a generic lambda the compiler lowers the step's selects to exec-mask branch
+// ladders (135 branches per block), and a branch inside the block costs the overlap between consecutive steps.  The block's
+// 16 costs and 16 values of the row above lane 0 are fetched first (one LDS round trip per block instead of one per step);
+// every lane stores every step -- lane 63 to bot[column] (column = t - 62 is hit exactly once per window; steps at which the
+// lane is not on a valid cell land in the padding), the others to a scratch strip -- because a conditional store would be a
+// branch again (228 cycles per step with it, 139 in the one-wave kernel that has none).
+#define RTS_WIN_DP_BLOCK(W1)                                                                                       \
+    {                                                                                                              \
+                double cbuf[16], ubuf[16]; \
+                int uxbuf[16]; \
+_Pragma("unroll") \
+                for (int q = 0; q < 16; q++) { \
+                    const int t = 16 * kb + q; \
+                    cbuf[q] = crow[t]; \
+                    ubuf[q] = upin[(t + 1 < m) ? t + 1 : 0]; \
+                    uxbuf[q] = (W1) ? botx[(t + 1 < m) ? t + 1 : 0] : 0; \
+                } \
+                double *bw = (lane == 63) ? bot + (16 * kb - 62) : bot_dummy + lane; \
+                int32_t *bxw = (lane == 63) ? botx + (16 * kb - 62) : botx_dummy + lane; \
+                word = 0; \
+_Pragma("unroll") \
+                for (int q = 0; q < 16; q++) { \
+                    const int t = 16 * kb + q; \
+                    const unsigned jj = (unsigned)(t - lane); \
+                    const bool incol = jj < (unsigned)mint; \
+                    const bool valid = incol && lane < rows; \
+                    const double du = sdp::shr1(dlast_v, ubuf[q]); \
+                    const int xu = sdp::shr1_i(xl, uxbuf[q]); \
+                    double dv; \
+                    int code; \
+                    sdp::WtwPolicy::cell(false, false, du, dlast_v, du_prev, cbuf[q], dv, code); \
+                    int xn = (code == sdp::kUp) ? xu : ((code == sdp::kDiag) ? xu_prev : xl); \
+                    const int xh = (code == sdp::kUp) ? (int)jj + 1 : ((code == sdp::kDiag) ? (int)jj : xl); \
+                    xn = is_h1 ? xh : xn; \
+                    du_prev = du; \
+                    xu_prev = xu; \
+                    word |= (uint32_t)code << (2 * q); \
+                    if (incol) { \
+                        dlast_v = dv; \
+                        xl = xn; \
+                    } \
+                    if constexpr (R > 1 && !(W1)) { /* only the first DP wave has a row to hand on */ \
+                        bw[q] = dv; \
+                        bxw[q] = xn; \
+                    } \
+                    if (STAGE && valid) dout[jj + 1] = dv; \
+                } \
+    }
+
 template <int R, bool STAGE>
 __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) {
     constexpr int NT = (R == 1) ? 256 : 512;  // two waves per SIMD for the wide windows: their cost phase is fp64-bound
@@ -541,53 +592,8 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
 #ifdef RTS_WIN_STAMPS
                 const long long blk_t0_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
-                // the block's 16 costs and 16 values of the row above lane 0 first (independent of the recurrence: one
-                // LDS round trip per block instead of one per step)
-                double cbuf[16], ubuf[16];
-                int uxbuf[16];
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int t = 16 * kb + q;
-                    cbuf[q] = crow[t];
-                    ubuf[q] = upin[(t + 1 < m) ? t + 1 : 0];
-                    uxbuf[q] = (R > 1 && r > 0) ? botx[(t + 1 < m) ? t + 1 : 0] : 0;
-                }
-                // Two DP waves: wave 0's bottom row goes to LDS for wave 1 WITHOUT a branch in the step -- a branch ends the
-                // basic block, and with it the compiler's freedom to overlap one step's selects with the next step's
-                // chain (measured: 228 cycles per step with the branch, 139 in the one-wave kernel that has none).  So
-                // every lane of both waves stores every step: lane 63 of wave 0 to bot[column] (column = t - 62 is hit
-                // exactly once per window; steps at which the lane is not on a valid cell land in the padding), everybody
-                // else to a scratch strip.
-                double *bw = (r == 0 && lane == 63) ? bot + (16 * kb - 62) : bot_dummy + lane;
-                int32_t *bxw = (r == 0 && lane == 63) ? botx + (16 * kb - 62) : botx_dummy + lane;
                 uint32_t word = 0;
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int t = 16 * kb + q;  // (steps past T - 1 compute and store nothing anybody reads)
-                    const unsigned jj = (unsigned)(t - lane);            // column - 1
-                    const bool incol = jj < (unsigned)mint;
-                    const bool valid = incol && lane < rows;
-                    const double du = sdp::shr1(dlast_v, ubuf[q]);        // D[i-1][j]; lane 0: from LDS
-                    const int xu = sdp::shr1_i(xl, uxbuf[q]);
-                    double dv;
-                    int code;
-                    sdp::WtwPolicy::cell(false, false, du, dlast_v, du_prev, cbuf[q], dv, code);  // wtw.py:201-215
-                    int xn = (code == sdp::kUp) ? xu : ((code == sdp::kDiag) ? xu_prev : xl);
-                    const int xh = (code == sdp::kUp) ? (int)jj + 1 : ((code == sdp::kDiag) ? (int)jj : xl);
-                    xn = is_h1 ? xh : xn;                                  // row h + 1: its predecessors in row h ARE the crossing
-                    du_prev = du;                                          // D[i-1][j-1] of the next step
-                    xu_prev = xu;
-                    word |= (uint32_t)code << (2 * q);                     // (codes of cells outside the matrix are never read)
-                    if (incol) {                                           // untouched before the lane's first and after its last cell
-                        dlast_v = dv;                                      // D[i][j-1] of the next step
-                        xl = xn;
-                    }
-                    if constexpr (R > 1) {
-                        bw[q] = dv;
-                        bxw[q] = xn;
-                    }
-                    if (STAGE && valid) dout[jj + 1] = dv;
-                }
+                if (R > 1 && r > 0) RTS_WIN_DP_BLOCK(true) else RTS_WIN_DP_BLOCK(false)
                 codes[((size_t)r * kWinKW + kb) * 64 + lane] = word;
 #ifdef RTS_WIN_STAMPS
                 if (b == 0 && lane == 0 && r < 2) g_win_stamps[6 + r] += (long long)__builtin_amdgcn_s_memtime() - blk_t0_;  // a DP wave's own block time
