@@ -321,19 +321,19 @@ __device__ long long g_win_stamps[8];
 #endif
 
 // One block of 16 DP steps of wtw_win_kernel, as a macro so that each DP wave gets its own straight-line copy (W1: this is the
-// second wave -- it fetches the crossing columns of wave 0's bottom row for its lane 0 and has no row to hand on; the first
+// second wave; NSTEP: 16, or 8 for a short last block -- it fetches the crossing columns of wave 0's bottom row for its lane 0 and has no row to hand on; the first
 // wave does the opposite).  Not a lambda: inside a generic lambda the compiler lowers the step's selects to exec-mask branch
 // ladders (135 branches per block), and a branch inside the block costs the overlap between consecutive steps.  The block's
 // 16 costs and 16 values of the row above lane 0 are fetched first (one LDS round trip per block instead of one per step);
 // every lane stores every step -- lane 63 to bot[column] (column = t - 62 is hit exactly once per window; steps at which the
 // lane is not on a valid cell land in the padding), the others to a scratch strip -- because a conditional store would be a
 // branch again (228 cycles per step with it, 139 in the one-wave kernel that has none).
-#define RTS_WIN_DP_BLOCK(W1)                                                                                       \
+#define RTS_WIN_DP_BLOCK(W1, NSTEP)                                                                                \
     {                                                                                                              \
                 double cbuf[16], ubuf[16]; \
                 int uxbuf[16]; \
 _Pragma("unroll") \
-                for (int q = 0; q < 16; q++) { \
+                for (int q = 0; q < (NSTEP); q++) { \
                     const int t = 16 * kb + q; \
                     cbuf[q] = crow[t]; \
                     ubuf[q] = upin[(t + 1 < m) ? t + 1 : 0]; \
@@ -343,7 +343,7 @@ _Pragma("unroll") \
                 int32_t *bxw = (lane == 63) ? botx + (16 * kb - 62) : botx_dummy + lane; \
                 word = 0; \
 _Pragma("unroll") \
-                for (int q = 0; q < 16; q++) { \
+                for (int q = 0; q < (NSTEP); q++) { \
                     const int t = 16 * kb + q; \
                     const unsigned jj = (unsigned)(t - lane); \
                     const bool incol = jj < (unsigned)mint; \
@@ -585,7 +585,9 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
             const double *upin = (r == 0) ? row0 : bot;                  // the row above this wave's lane 0
             double *dout = STAGE ? g.dlast + ((size_t)b * W + ic) * W : nullptr;
             const double *crow = C + (size_t)ic * ldc + 1 - lane;         // crow[t] = C[i][1 + t - lane]
-            for (int k = 0; k < rounds_all; k++) {
+            const bool short_tail = (R == 1) && blocks > 0 && (T - 16 * (blocks - 1) <= 8);  // wave-uniform
+            const int loop_rounds = short_tail ? rounds_all - 1 : rounds_all;
+            for (int k = 0; k < loop_rounds; k++) {
                 if (R > 1) lds_barrier();  // wave 1 reads bottom-row values wave 0 wrote at least one round ago
                 const int kb = k - 5 * r;
                 if (kb < 0 || kb >= blocks) continue;  // wave-uniform
@@ -593,11 +595,17 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
                 const long long blk_t0_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
                 uint32_t word = 0;
-                if (R > 1 && r > 0) RTS_WIN_DP_BLOCK(true) else RTS_WIN_DP_BLOCK(false)
+                if (R > 1 && r > 0) RTS_WIN_DP_BLOCK(true, 16) else RTS_WIN_DP_BLOCK(false, 16)
                 codes[((size_t)r * kWinKW + kb) * 64 + lane] = word;
 #ifdef RTS_WIN_STAMPS
                 if (b == 0 && lane == 0 && r < 2) g_win_stamps[6 + r] += (long long)__builtin_amdgcn_s_memtime() - blk_t0_;  // a DP wave's own block time
 #endif
+            }
+            if (short_tail) {  // one DP wave: a last block of at most 8 steps runs as 8 (tests.py:174's 20-frame windows sweep 37 steps)
+                const int kb = blocks - 1;
+                uint32_t word = 0;
+                RTS_WIN_DP_BLOCK(false, 8)
+                codes[((size_t)r * kWinKW + kb) * 64 + lane] = word;
             }
             if (r < R && lane < rows && i == n - 1) sh[2] = xl;  // the last cell's crossing column
         }
