@@ -296,12 +296,20 @@ constexpr int kWinPadBack = 208;  // (and ignore) whatever their row pointer + s
 constexpr int kWinBotFront = 64, kWinBotBack = 32, kWinBotDummy = 80;
 constexpr int kWinBotPad = kWinBotFront + kWinBotBack + kWinBotDummy;
 
+// Windows of at most kWinPrefW frames (tests.py:174: 20): while the DP of window k runs, the idle cost waves fetch what the
+// cost phase of window k + 1 will need -- its live rows (live_ptr + hop is known) into xs / nx, and the 128 reference frames
+// from ref_ptr on (the next window starts at ref_ptr + r*, r* < W, so its columns are among them) into ypre / nypre -- so
+// that phase A reads LDS instead of waiting for L2 (3 k of the 5 k cycles of a 20-frame window's cost phase).
+constexpr int kWinPrefW = 64;   // (the one-wave kernel's whole range)
+constexpr int kWinPrefN = 128;  // reference frames fetched: two per lane of the fetching waves
+
 __host__ __device__ inline int win_ldc(int W) { return (W | 1) + 1; }  // even > W: lanes a row apart hit different LDS banks
 __host__ __device__ inline size_t win_lds_bytes(int W) {
     const size_t feat = sizeof(double) * ((size_t)W * kWF + (size_t)W);                    // xs, nx
     const size_t walk = sizeof(uint32_t) * 2 * kWinKW * 64 + sizeof(double) * (3 * (size_t)W + 32 + kWinBotPad) +  // codes; row 0, column 0 (padded), bottom row of wave 0 (padded)
                         sizeof(int32_t) * ((size_t)W + kWinBotPad) + sizeof(int32_t) * 4 * (size_t)W;  // its crossing columns (padded); sub-path
-    return sizeof(double) * ((size_t)W * win_ldc(W) + kWinPadFront + kWinPadBack) + feat + walk + 128;
+    const size_t pref = (W <= kWinPrefW) ? sizeof(double) * (kWinPrefN * kWF + kWinPrefN) : 0;  // ypre, nypre
+    return sizeof(double) * ((size_t)W * win_ldc(W) + kWinPadFront + kWinPadBack) + feat + walk + pref + 128;
 }
 
 #ifdef RTS_WIN_STAMPS
@@ -391,6 +399,8 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
     int32_t *botx = reinterpret_cast<int32_t *>(bot_dummy + kWinBotDummy) + kWinBotFront;  // [W] ... and its crossing columns, padded
     int32_t *botx_dummy = botx + W + kWinBotBack;                                 // [80]
     int32_t *sub = botx_dummy + kWinBotDummy;                                     // [2W][2], reversed
+    double *ypre = reinterpret_cast<double *>(sub + 4 * (size_t)W);              // [kWinPrefN][F] reference frames pref_rp .. (W <= kWinPrefW)
+    double *nypre = ypre + kWinPrefN * kWF;                                       // [kWinPrefN] their norms
 
     int32_t *st = g.state + (size_t)b * 8;
     const double *live = g.live + (size_t)b * g.N * kWF;
@@ -402,6 +412,7 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
     long long cells = ((long long)(uint32_t)st[7] << 32) | (uint32_t)st[6];
     // the window whose path wave 0 still has to walk: its pointers and where the walk starts
     int have_prev = 0, plp = 0, prp = 0, pwi = 0, pwj = 0;
+    int have_pref = 0, pref_lp = 0, pref_rp = 0;  // what the cost waves fetched during the last DP phase
     const int h = g.hopf;
 
     for (;;) {
@@ -483,24 +494,34 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
             const long long c0_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
             const int cwv = wave - 1;
-            // my columns' reference frames first (their latency hides behind the staging of the rows)
             double y0[kWF], y1[kWF];
-            sdp::load_frame(g.ref, 1, (long long)rp + (lane < m ? lane : m - 1), y0);
-            if (m > 64) sdp::load_frame(g.ref, 1, (long long)rp + (64 + lane < m ? 64 + lane : m - 1), y1);
-            // my rows (cwv, cwv + NCW, ...) into my slice of xs / nx: wave-private, no barrier
+            double ny0;
             const int nrows = (n - cwv + NCW - 1) / NCW;
-            for (int q = lane; q < nrows * kWF; q += 64) {
-                const int row = cwv + NCW * (q / kWF);
-                xs[row * kWF + q % kWF] = live[(size_t)(lp + row) * kWF + q % kWF];
-            }
-            for (int q = lane; q < nrows; q += 64) {
-                const int row = cwv + NCW * q;
-                double x[kWF];
+            // (uniform) everything this window needs was fetched during the previous window's DP phase
+            const bool pref = (R == 1) && W <= kWinPrefW && have_pref && lp == pref_lp && rp >= pref_rp && rp - pref_rp + m <= kWinPrefN;
+            if (pref) {
+                const int off = rp - pref_rp + (lane < m ? lane : m - 1);
 #pragma unroll
-                for (int f = 0; f < kWF; f++) x[f] = xs[row * kWF + f];
-                nx[row] = sdp::WtwPolicy::norm(x);
+                for (int f = 0; f < kWF; f++) y0[f] = ypre[off * kWF + f];
+                ny0 = nypre[off];
+            } else {
+                // my columns' reference frames first (their latency hides behind the staging of the rows)
+                sdp::load_frame(g.ref, 1, (long long)rp + (lane < m ? lane : m - 1), y0);
+                if (m > 64) sdp::load_frame(g.ref, 1, (long long)rp + (64 + lane < m ? 64 + lane : m - 1), y1);
+                // my rows (cwv, cwv + NCW, ...) into my slice of xs / nx: wave-private, no barrier
+                for (int q = lane; q < nrows * kWF; q += 64) {
+                    const int row = cwv + NCW * (q / kWF);
+                    xs[row * kWF + q % kWF] = live[(size_t)(lp + row) * kWF + q % kWF];
+                }
+                for (int q = lane; q < nrows; q += 64) {
+                    const int row = cwv + NCW * q;
+                    double x[kWF];
+#pragma unroll
+                    for (int f = 0; f < kWF; f++) x[f] = xs[row * kWF + f];
+                    nx[row] = sdp::WtwPolicy::norm(x);
+                }
+                ny0 = sdp::WtwPolicy::norm(y0);
             }
-            const double ny0 = sdp::WtwPolicy::norm(y0);
             const double ny1 = (m > 64) ? sdp::WtwPolicy::norm(y1) : 1.0;
             for (int i = cwv; i < n; i += NCW) {
                 double x[kWF];
@@ -565,6 +586,30 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
         RTS_WIN_STAMP(1);
         // ---- C. interior DP: lane l of wave r owns row 1 + 64 r + l, column 1 + t - l at local step t
         const bool has_cross = h + 1 <= n - 1;  // the path goes below row h: wtw.py:118-124's "change"
+        if (R == 1 && W <= kWinPrefW && wave >= 1) {  // the idle cost waves: what the next window's cost phase will read (see kWinPrefW)
+            const int cwv = wave - 1, nlp = lp + h;
+            const int nrows = (n - cwv + NCW - 1) / NCW;
+            for (int q = lane; q < nrows * kWF; q += 64) {
+                const int row = cwv + NCW * (q / kWF);
+                const int fr = (nlp + row < g.N) ? nlp + row : g.N - 1;
+                xs[row * kWF + q % kWF] = live[(size_t)fr * kWF + q % kWF];
+            }
+            for (int q = lane; q < nrows; q += 64) {
+                const int row = cwv + NCW * q;
+                double x[kWF];
+#pragma unroll
+                for (int f = 0; f < kWF; f++) x[f] = xs[row * kWF + f];
+                nx[row] = sdp::WtwPolicy::norm(x);
+            }
+            if (wave <= 2) {  // waves 1 and 2: 64 reference frames each
+                const int slot = 64 * (wave - 1) + lane;
+                double yv[kWF];
+                sdp::load_frame(g.ref, 1, (long long)((rp + slot < g.M) ? rp + slot : g.M - 1), yv);
+#pragma unroll
+                for (int f = 0; f < kWF; f++) ypre[slot * kWF + f] = yv[f];
+                nypre[slot] = sdp::WtwPolicy::norm(yv);
+            }
+        }
         {
             const int r = wave;
             const int nint = n - 1, mint = m - 1;                       // interior rows / columns
@@ -613,6 +658,9 @@ __global__ void __launch_bounds__(R == 1 ? 256 : 512) wtw_win_kernel(WtwArgs g) 
         RTS_WIN_STAMP(2);
         // ---- the next window's pointers (wtw.py:118-128), and what wave 0 walks during the next phase A
         const int xstar = (has_cross && m > 1) ? sh[2] : 0;  // (m == 1: the path is column 0)
+        have_pref = (R == 1 && W <= kWinPrefW) ? 1 : 0;
+        pref_lp = lp + h;
+        pref_rp = rp;
         plp = lp;
         prp = rp;
         pwi = has_cross ? h : n - 1;
